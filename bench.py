@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""bench.py -- MDoF/s per V-cycle on 2-D Poisson (BASELINE.json metric), MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload at N=1: BASELINE config 3, the configuration north_star quotes the roofline target on:
+2-D Poisson 4097^2, V(2,2) weighted Jacobi (omega 0.8), 11 levels (coarsest 5x5), adaptive
+fp32 -> fp64 with switch_threshold 1e-6, f = 2 pi^2 sin(pi x) sin(pi y), u0 = 0 (synthetic).
+One step = one V-cycle of the solve loop (policy check, cycle, ||r||) with all fields resident in HBM.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def sine_rhs(nx, ny, dtype=np.float64):
+    x = np.linspace(0.0, 1.0, nx)
+    y = np.linspace(0.0, 1.0, ny)
+    return (2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * y)[None, :]).astype(dtype)
+
+
+def cpu_baseline(n, levels, seconds_budget=20.0):
+    """The oracle (NumPy restatement of the reference's CPU V-cycle, 1 core) timed on this host on a
+    bounded sample of the same workload: whole V(2,2) Jacobi cycles at n^2 in fp64."""
+    from oracle import mg_oracle as O
+    mgo = O.MGOracle(n, n, max_levels=levels, cycle="V", smoother="jacobi", omega=0.8, jacobi_form="vectorized")
+    rhs = O.sine_rhs(n, n)
+    mgo.rhs[0] = rhs.copy()
+    u = np.zeros_like(rhs)
+    cycles, t0 = 0, time.time()
+    while True:
+        u = mgo.cycle_once(u, 0)
+        cycles += 1
+        el = time.time() - t0
+        if el > seconds_budget or cycles >= 8:
+            break
+    return {"value": n * n * cycles / el / 1e6, "unit": "MDoF/s per V-cycle", "cores": 1, "kind": "port",
+            "sample": f"{cycles} V(2,2) Jacobi cycles of the {n}^2 fp64 problem, NumPy oracle, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=4097, help="grid points per direction per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        from mixed_precision_multigrid_solvers_for_pdes_amd import distributed as dist_mg
+        return dist_mg.bench_main(args, rank, local_rank, world)
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    import mixed_precision_multigrid_solvers_for_pdes_amd as mg
+    from mixed_precision_multigrid_solvers_for_pdes_amd import _lib
+
+    n, K, W = args.n, args.steps, args.warmup
+    levels = mg.default_max_levels(n, n)
+    eng = mg.MultigridEngine(n, n, max_levels=levels, cycle="V", pre=2, post=2, smoother=_lib.MG_JACOBI, omega=0.8,
+                             precision=_lib.MG_PREC_ADAPTIVE, switch_threshold=1e-6, adaptive_reference_rule=False,
+                             device=local_rank)
+    eng.set_rhs(sine_rhs(n, n))
+    eng.set_solution(None)
+    if W > 0:
+        eng.iterate(tol=0.0, max_iterations=W)            # untimed warm-up steps
+    eng.set_solution(None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = eng.iterate(tol=0.0, max_iterations=K)            # exactly K steps
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    value = n * n * K / dt / 1e6
+    hist = r["residual_history"]
+    codes = r["precision_codes"]
+
+    # per-precision cycle rates and the roofline leg: hipEvent-timed launches on the engine's own stream
+    reps = 50
+    ms_j32 = eng.time_op("jacobi", 0, np.float32, reps)
+    ms_j64 = eng.time_op("jacobi", 0, np.float64, reps)
+    bytes32, bytes64 = 3 * 4 * n * n, 3 * 8 * n * n        # read u, read rhs, write u' 
+    f32_cycles = sum(1 for c in codes if c == 0)
+    dominant_f32 = f32_cycles * ms_j32 >= (K - f32_cycles) * ms_j64
+    ach32, ach64 = bytes32 / (ms_j32 * 1e-3) / 1e9, bytes64 / (ms_j64 * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "jacobi_kernel<float,1> (4097^2 fp32 sweep)", "achieved": ach32,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach32 / HBM_PEAK_GBS, "traffic": None,
+            "launch_ms": ms_j32, "algorithmic_bytes_per_launch": bytes32,
+            "fp64": {"kernel": "jacobi_kernel<double,1>", "achieved": ach64, "frac": ach64 / HBM_PEAK_GBS,
+                     "launch_ms": ms_j64, "algorithmic_bytes_per_launch": bytes64},
+            "dominant_in_timed_region": "fp32" if dominant_f32 else "fp64"}
+
+    out = {
+        "metric": "MDoF/s per V-cycle", "value": value, "unit": "MDoF/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32->f64 (adaptive)", "data": "synthetic",
+        "config": {"workload": f"2D Poisson {n}^2 adaptive fp32->fp64 (switch_threshold=1e-6), V(2,2) weighted-Jacobi "
+                               f"omega=0.8, {levels} levels, 1xMI355X", "grid": [n, n], "levels": levels,
+                   "cycle": "V(2,2)", "smoother": "jacobi", "parallelism": "1 GPU"},
+        "cycles_fp32": f32_cycles, "cycles_fp64": K - f32_cycles,
+        "residual_first": hist[0], "residual_last": hist[-1],
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, levels)
+    eng.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+/*
+ * mghip -- C ABI of the MI355X-native geometric-multigrid hot path.
+ *
+ * This is the drop-in boundary for the reference's V/W-cycle path
+ * (Tani843/Mixed_Precision_Multigrid_Solvers_for_PDEs).  The reference is pure
+ * Python; the calls a maintainer would re-bind through ctypes are listed on each
+ * entry point as "replaces: <file:line>" (paths relative to the reference's
+ * src/multigrid/).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every function returns an int status: MG_OK (0) or a negative MG_ERR_*;
+ *     the message of the last failure is available from mg_last_error();
+ *   - host arrays are dense C-order (nx, ny), j contiguous (core/grid.py:50),
+ *     owned by the caller, never retained or modified by the library;
+ *   - device arrays (mg_dev_*) are (nx, ny) with a row pitch `ld` in ELEMENTS,
+ *     base 16-byte aligned and ld a multiple of 16 bytes (4 f32 / 2 f64);
+ *   - calls are blocking unless stated otherwise; a handle is not thread-safe;
+ *   - dtype arguments are mg_dtype values; fp32 fields are processed in fp32 and
+ *     fp64 fields in fp64, exactly like NumPy does for the reference.
+ */
+#ifndef MGHIP_H
+#define MGHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK 0
+#define MG_ERR_INVALID_VALUE (-1) /* -> ValueError (core/grid.py:34-35,148-149; operators/laplacian.py:61-62; operators/transfer.py:65-69,201-205) */
+#define MG_ERR_NO_DEVICE (-2)     /* -> RuntimeError; the reference raises ImportError("CuPy is required") gpu/gpu_solver.py:64-65 */
+#define MG_ERR_HIP (-3)           /* -> RuntimeError: a HIP call failed */
+#define MG_ERR_STATE (-4)         /* -> ValueError("Multigrid not properly setup or grid mismatch") solvers/multigrid.py:205-206 */
+#define MG_ERR_ALLOC (-5)         /* -> MemoryError */
+
+typedef enum { MG_F32 = 0, MG_F64 = 1 } mg_dtype;
+typedef enum {
+  MG_JACOBI = 0, /* weighted Jacobi            solvers/smoothers.py:41-86, solvers/iterative.py:72-108 */
+  MG_RBGS = 1,   /* red-black Gauss-Seidel     solvers/smoothers.py:175-207                          */
+  MG_LEXGS = 2   /* lexicographic Gauss-Seidel solvers/smoothers.py:153-173 -- sequential by nature:
+                    one workgroup sweeps anti-diagonals; exact, meant for small grids / the coarsest level */
+} mg_smoother_t;
+typedef enum { MG_CYCLE_V = 0, MG_CYCLE_W = 1, MG_CYCLE_F = 2 } mg_cycle_t;
+typedef enum {
+  MG_PREC_DOUBLE = 0,       /* Grid(dtype=float64), no precision manager                       */
+  MG_PREC_SINGLE = 1,       /* Grid(dtype=float32)                                             */
+  MG_PREC_MIXED_LEVELS = 2, /* PrecisionManager('mixed'): level >= L//2 fp32 (core/precision.py:337-357) */
+  MG_PREC_ADAPTIVE = 3      /* threshold switch fp32 <-> fp64 (core/precision.py:270-302)      */
+} mg_precision_t;
+
+/* Packed solver configuration: the constructor kwargs of MultigridSolver
+ * (solvers/multigrid.py:36-47) / GPUMultigridSolver (gpu/gpu_solver.py:32-46), the Grid
+ * (core/grid.py:18-44), LaplacianOperator.coefficient (operators/laplacian.py:22) and the
+ * PrecisionManager thresholds (core/precision.py:26-45). */
+typedef struct mg_config {
+  int32_t nx, ny;            /* fine grid points incl. boundary                                 */
+  double x0, x1, y0, y1;     /* domain; hx = (x1-x0)/(nx-1)                                     */
+  double coeff;              /* operator A = coeff * Laplacian_h; the consistent choice is -1   */
+  int32_t max_levels;        /* hierarchy stops earlier at coarse n < 5 or odd (n-1)            */
+  int32_t cycle;             /* mg_cycle_t                                                      */
+  int32_t pre, post;         /* smoothing sweeps                                                */
+  int32_t smoother;          /* mg_smoother_t                                                   */
+  double omega;              /* relaxation parameter                                            */
+  double coarse_tol;         /* coarsest lex-GS: stop at ||r|| < coarse_tol ...                 */
+  int32_t coarse_maxit;      /* ... or after this many sweeps                                   */
+  int32_t precision;         /* mg_precision_t                                                  */
+  double switch_threshold;   /* PrecisionManager.convergence_threshold                          */
+  double memory_threshold_gb;/* PrecisionManager.memory_threshold_gb                            */
+  int32_t adaptive_reference_rule; /* 1: the reference's two-way rule verbatim (never recovers);
+                                      0: one-way fp32 -> fp64 at ||r|| < 10*thr or on fp32 stagnation    */
+  int32_t device;            /* HIP device ordinal                                              */
+  int32_t profile;           /* 1: per-level stage timings (synchronising; solvers/multigrid.py:179-182) */
+  int32_t colour_offset;     /* parity of the global index of local cell (0,0) (sub-domains)     */
+} mg_config;
+
+typedef struct mg_stats {
+  double solve_seconds;      /* device-resident cycles + norms                (gpu_solve_time)  */
+  double h2d_seconds;        /* rhs / initial guess upload                    (gpu_transfer_time, part) */
+  double d2h_seconds;        /* solution download                                               */
+  double initial_residual;   /* ||f - A u0||                                  (gpu/gpu_solver.py:243-251) */
+  int32_t precision_switches;
+  int32_t last_coarse_sweeps;
+} mg_stats;
+
+typedef struct mg_handle mg_handle;
+
+/* ---- library / device ------------------------------------------------------------------ */
+const char* mg_version(void);
+int mg_device_count(int* count);
+/* message of the last error on this handle (NULL: last error of a handle-less call). */
+const char* mg_last_error(const mg_handle* h);
+
+/* ---- solver object: replaces GPUMultigridSolver.setup/solve/cleanup ---------------------- */
+/* replaces: gpu/gpu_solver.py:116-184 (setup: hierarchy + per-level device arrays), solvers/multigrid.py:135-182 */
+int mg_create(const mg_config* cfg, mg_handle** out);
+/* replaces: gpu/gpu_solver.py:483-501 (cleanup) */
+int mg_destroy(mg_handle* h);
+int mg_num_levels(const mg_handle* h, int* n);
+int mg_level_shape(const mg_handle* h, int level, int* nx, int* ny);
+/* accumulated seconds {smooth, restrict, prolong} of `level` when cfg.profile = 1 (solvers/multigrid.py:289-335) */
+int mg_level_timings(const mg_handle* h, int level, double out3[3]);
+
+/* replaces: gpu/gpu_solver.py:186-328 and solvers/multigrid.py:184-251.
+ * rhs, u0 (nullable) and u_out are host arrays of host_dtype.  hist receives one ||r|| per cycle
+ * (at most hist_cap), prec_hist (nullable) the working precision of each cycle (mg_dtype, or 2 for
+ * per-level mixed).  Stops when ||r|| < tol (absolute, solvers/base.py:134) or after max_iter cycles. */
+int mg_solve(mg_handle* h, const void* rhs, const void* u0, void* u_out, int host_dtype, double tol,
+             int max_iter, double* hist, int hist_cap, int* n_iter, int* converged, int32_t* prec_hist,
+             mg_stats* stats);
+
+/* The iteration loop of mg_solve alone, on the rhs / iterate already resident on the device
+ * (mg_set_rhs, mg_set_solution): policy check, cycle, ||r||, repeated; no host transfer of fields.
+ * replaces: the loop body of solvers/multigrid.py:219-246 / gpu/gpu_solver.py:254-297 */
+int mg_iterate(mg_handle* h, double tol, int max_iter, double* hist, int hist_cap, int* n_iter, int* converged,
+               int32_t* prec_hist, mg_stats* stats);
+
+/* Device-resident stepping (benchmarks, preconditioner-style callers: fixed cycle counts, no transfer). */
+int mg_set_rhs(mg_handle* h, const void* rhs, int host_dtype);
+int mg_set_solution(mg_handle* h, const void* u0_or_null, int host_dtype);
+int mg_get_solution(mg_handle* h, void* u_out, int host_dtype);
+int mg_cycle(mg_handle* h, int ncycles);           /* asynchronous on the handle's stream        */
+int mg_residual_norm(mg_handle* h, double* out);   /* sqrt(hx*hy*sum r^2), synchronises           */
+int mg_set_working_precision(mg_handle* h, int dtype); /* MG_PREC_ADAPTIVE only: in-device cast of u */
+int mg_synchronize(mg_handle* h);
+/* the stream all of the handle's work is queued on (a hipStream_t), for callers that bracket with events */
+int mg_get_stream(mg_handle* h, void** stream);
+
+/* hipEvent-timed repetitions of one kernel of the path on the handle's own arrays and stream
+ * (used by bench.py for the roofline line).  op: 0 jacobi sweep, 1 rbgs sweep (both colours),
+ * 2 residual (store r), 3 residual+norm (no store), 4 restrict, 5 prolong+add, 6 whole cycle.
+ * dtype selects the precision of `level`'s arrays (must be allocated under cfg.precision). */
+int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg_ms);
+
+/* ---- stateless operators on HOST arrays (upload, run the HIP kernel, download) ----------- */
+/* replaces: operators/laplacian.py:105-124 / gpu/cuda_kernels.py:794-828 (TransferKernels.compute_residual) */
+int mg_op_residual(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* u, const void* f, void* r);
+/* replaces: operators/laplacian.py:44-80 (apply = f - residual with f = 0, sign folded) */
+int mg_op_apply(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* u, void* au);
+/* replaces: core/grid.py:174-187 (Grid.l2_norm) */
+int mg_op_norm(int dtype, int nx, int ny, double hx, double hy, const void* field, double* out);
+/* replaces: solvers/smoothers.py:41-86, solvers/iterative.py:72-108, gpu/cuda_kernels.py:284-346 (jacobi_smoothing) */
+int mg_op_jacobi(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* u, const void* rhs, void* out);
+/* replaces: solvers/smoothers.py:117-151,175-207, gpu/cuda_kernels.py:348-390 (red_black_gauss_seidel) */
+int mg_op_rbgs(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* u, const void* rhs, void* out);
+/* replaces: operators/transfer.py:53-81,100-124, gpu/cuda_kernels.py:738-764 (TransferKernels.restriction) */
+int mg_op_restrict_fw(int in_dtype, int out_dtype, int nx, int ny, const void* fine, void* coarse);
+/* replaces: operators/transfer.py:189-215,234-267, gpu/cuda_kernels.py:766-792 (TransferKernels.prolongation) */
+int mg_op_prolong_bilinear(int in_dtype, int out_dtype, int ncx, int ncy, const void* coarse, void* fine);
+/* replaces: solvers/smoothers.py:153-173 under solvers/base.py:234-290 (coarsest-grid solve) */
+int mg_op_coarse_solve(int dtype, int nx, int ny, double hx, double hy, double coeff, double tol, int maxit,
+                       const void* u0, const void* rhs, void* out, int* sweeps);
+
+/* ---- stateless operators on DEVICE arrays (asynchronous on `stream`, a hipStream_t or NULL) -- */
+int mg_dev_jacobi(int dtype, int nx, int ny, int ld, double hx, double hy, double omega,
+                  const void* u, const void* rhs, void* out, void* stream);
+int mg_dev_rbgs_colour(int dtype, int nx, int ny, int ld, double hx, double hy, double omega, int colour,
+                       int colour_offset, void* u, const void* rhs, void* stream);
+int mg_dev_residual(int dtype, int nx, int ny, int ld, double hx, double hy, double coeff,
+                    const void* u, const void* f, void* r, void* stream);
+/* sum of squares into *sumsq_dev (one double in device memory); scratch >= mg_dev_scratch_bytes() */
+int mg_dev_sumsq(int dtype, int nx, int ny, int ld, const void* field, void* scratch, double* sumsq_dev, void* stream);
+int mg_dev_restrict_fw(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int ldc,
+                       const void* fine, void* coarse, void* stream);
+int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int nxf, int nyf, int ldf, int ldc,
+                       const void* coarse, void* fine_u, void* stream);
+int mg_dev_convert(int in_dtype, int out_dtype, int nx, int ny, int ldi, int ldo, const void* in, void* out, void* stream);
+int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes);
+/* pitch (elements) the library itself uses for an (nx, ny) field of `dtype` */
+int mg_pitch_elems(int dtype, int ny, int* ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGHIP_H */

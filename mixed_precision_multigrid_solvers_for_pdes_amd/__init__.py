@@ -1,0 +1,25 @@
+"""MI355X-native mixed-precision geometric multigrid: the V/W-cycle hot path of
+Tani843/Mixed_Precision_Multigrid_Solvers_for_PDEs behind that project's own Python API.
+
+Host side (this package): metadata, policy and the plugin classes of the reference
+(Grid, LaplacianOperator, RestrictionOperator, ProlongationOperator, smoothers, PrecisionManager,
+MultigridSolver, GPUMultigridSolver) plus the README facade (MixedPrecisionMultigrid,
+PoissonProblem).  Device side: csrc/ -> lib/libmghip.so, reached through the C ABI in
+include/mghip.h.  There is no CPU fallback for the device path."""
+from .grid import Grid
+from .operators import BaseOperator, LaplacianOperator, ProlongationOperator, RestrictionOperator
+from .precision import PrecisionLevel, PrecisionManager
+from .smoothers import (BaseSolver, ConvergenceHistory, EnhancedJacobiSolver, GaussSeidelSmoother,
+                        IterativeSolver, JacobiSmoother, WeightedJacobiSmoother)
+from .solver import GPUMultigridSolver, MultigridCycle, MultigridSolver
+from .engine import MultigridEngine
+from .facade import MixedPrecisionMultigrid, PoissonProblem, default_max_levels
+
+__all__ = [
+    "Grid", "BaseOperator", "LaplacianOperator", "RestrictionOperator", "ProlongationOperator",
+    "PrecisionLevel", "PrecisionManager", "BaseSolver", "ConvergenceHistory", "IterativeSolver",
+    "JacobiSmoother", "WeightedJacobiSmoother", "EnhancedJacobiSolver", "GaussSeidelSmoother",
+    "MultigridSolver", "GPUMultigridSolver", "MultigridCycle", "MultigridEngine",
+    "MixedPrecisionMultigrid", "PoissonProblem", "default_max_levels",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,464 @@
+// CDNA4 (gfx950) kernels of the geometric-multigrid V/W-cycle hot path.
+//
+// Layout of every field: logical shape (nx, ny), C order, index [i][j] with j
+// contiguous (reference: core/grid.py:50 meshgrid 'ij'); element (i,j) lives at
+// base + i*ld + j where ld (the row pitch, in elements) is a multiple of one
+// 16-byte vector and base is 16-byte aligned, so every row starts on a vector
+// boundary and each lane moves 16 B per access.  Columns [ny, ld) are padding:
+// kernels carry them through unchanged and reductions mask them out.
+//
+// Stencil kernels stage a (TI+2) x (TJ+2 vectors) tile of u -- the tile plus its
+// 1-cell halo ring -- through LDS, so each u element is fetched from L2/HBM once
+// per tile; rhs and the output move register <-> HBM as whole vectors.  The
+// blockIdx -> tile map is XCD-aware: each of the 8 XCDs sweeps a contiguous band
+// of tile rows, so the vertical halo re-reads hit that XCD's own L2.
+//
+// Arithmetic follows the reference's association order exactly (file:line on
+// each kernel); the build uses -ffp-contract=off so no FMA contraction changes
+// a rounding.  Divisions by hx^2, hy^2 and the diagonal are multiplications by
+// host-computed reciprocals: identical bits when h^2 is a power of two (every
+// 2^k+1 grid on a unit-length domain), <= 1 ulp per operation otherwise.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace mg {
+
+constexpr int kBlock = 256;          // 4 wave64
+constexpr int kTileRowBytes = 512;   // bytes of one tile row (128 f32 / 64 f64)
+constexpr int kTI = 32;              // tile rows
+constexpr int kNumXcd = 8;
+// TAG values of the tile kernels: same code, distinct symbols, so that a kernel trace (rocprofv3 --stats)
+// reports the finest-level launches separately from the many small coarse-level ones.
+constexpr int kCoarseTag = 0, kFineTag = 1;
+
+template <typename T> struct VecW { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> struct alignas(16) Pack {
+  T v[VecW<T>::N];
+};
+
+template <typename T> __device__ __forceinline__ Pack<T> ldg(const T* p) {
+  return *reinterpret_cast<const Pack<T>*>(p);
+}
+template <typename T> __device__ __forceinline__ void stg(T* p, const Pack<T>& x) {
+  *reinterpret_cast<Pack<T>*>(p) = x;
+}
+template <typename T> __device__ __forceinline__ Pack<T> zero_pack() {
+  Pack<T> z;
+#pragma unroll
+  for (int e = 0; e < VecW<T>::N; ++e) z.v[e] = T(0);
+  return z;
+}
+
+// Bijective XCD-aware remap (blocks b and b+8 share an XCD under round-robin
+// dispatch; speed only, never correctness): logical ids are dealt so that XCD k
+// owns the contiguous range [k*q + min(k,r), ...).
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n / kNumXcd, r = n % kNumXcd;
+  const int x = b % kNumXcd, idx = b / kNumXcd;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + idx;
+}
+
+struct TileGeom {
+  int nx, ny, ld;        // logical rows, logical cols, pitch (elements)
+  int nyv;               // ny rounded up to one vector: columns >= nyv are never touched
+  int i_org;             // row of the first tile (0: cover the boundary rows too, 1: interior rows only)
+  int tiles_j, ntiles;   // tile grid
+};
+
+template <typename T> struct TileShape {
+  static constexpr int N = VecW<T>::N;
+  static constexpr int TJ = kTileRowBytes / (int)sizeof(T);   // tile columns
+  static constexpr int SJ = TJ + 2 * N;                       // LDS row stride (elements)
+  static constexpr int VPR = SJ / N;                          // vectors per LDS row
+  static constexpr int CG = TJ / N;                           // column groups (threads per tile row) = 32
+  static constexpr int RG = kBlock / CG;                      // row groups = 8
+  static constexpr int RPT = kTI / RG;                        // rows per thread = 4
+  static constexpr int LDS_ELEMS = (kTI + 2) * SJ;
+};
+
+// Stage rows [i0-1, i0+TI] x cols [j0-N, j0+TJ+N) of `u` into LDS (zeros outside the array).
+template <typename T>
+__device__ __forceinline__ void stage_tile(const T* __restrict__ u, T* __restrict__ s, int i0, int j0,
+                                           int nx, int nyv, int ld) {
+  using S = TileShape<T>;
+  for (int v = threadIdx.x; v < (kTI + 2) * S::VPR; v += kBlock) {
+    const int r = v / S::VPR, c = v - r * S::VPR;
+    const int gi = i0 - 1 + r, gj = j0 - S::N + c * S::N;
+    Pack<T> p = zero_pack<T>();
+    if (gi >= 0 && gi < nx && gj >= 0 && gj < nyv) p = ldg(u + (size_t)gi * ld + gj);
+    *reinterpret_cast<Pack<T>*>(s + r * S::SJ + c * S::N) = p;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Weighted Jacobi, one sweep, out of place.
+//   reference: solvers/smoothers.py:62-84 (loop form), solvers/iterative.py:84-104 (vectorised):
+//     nb = ihx2*(u[i+1,j]+u[i-1,j]) + ihy2*(u[i,j+1]+u[i,j-1]);  un = (rhs+nb)/D;
+//     out = (1-w)*u + w*un on interior cells; boundary cells copied through.
+//   algorithmic traffic: read u, read rhs, write out = 3 words / DoF.
+// --------------------------------------------------------------------------------------------
+template <typename T, int TAG>
+__global__ __launch_bounds__(kBlock) void jacobi_kernel(const T* __restrict__ u, const T* __restrict__ rhs,
+                                                        T* __restrict__ out, TileGeom g, T ihx2, T ihy2, T invD,
+                                                        T omega, T one_m_omega) {
+  using S = TileShape<T>;
+  __shared__ __attribute__((aligned(16))) T s[S::LDS_ELEMS];
+  const int L = xcd_remap(blockIdx.x, g.ntiles);
+  const int ti = L / g.tiles_j, tj = L - ti * g.tiles_j;
+  const int i0 = g.i_org + ti * kTI, j0 = tj * S::TJ;
+  const int cg = threadIdx.x % S::CG, rg = threadIdx.x / S::CG;
+  const int gj0 = j0 + cg * S::N;
+  const int lr = rg * S::RPT;
+
+  Pack<T> f[S::RPT];
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const int gi = i0 + lr + k;
+    f[k] = (gi < g.nx && gj0 < g.nyv) ? ldg(rhs + (size_t)gi * g.ld + gj0) : zero_pack<T>();
+  }
+  stage_tile<T>(u, s, i0, j0, g.nx, g.nyv, g.ld);
+  __syncthreads();
+
+  const int lc = S::N + cg * S::N;
+  Pack<T> up = *reinterpret_cast<const Pack<T>*>(s + (lr + 0) * S::SJ + lc);
+  Pack<T> mid = *reinterpret_cast<const Pack<T>*>(s + (lr + 1) * S::SJ + lc);
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const Pack<T> dn = *reinterpret_cast<const Pack<T>*>(s + (lr + k + 2) * S::SJ + lc);
+    const T left = s[(lr + k + 1) * S::SJ + lc - 1];
+    const T right = s[(lr + k + 1) * S::SJ + lc + S::N];
+    const int gi = i0 + lr + k;
+    const bool row_in = (gi >= 1) && (gi < g.nx - 1);
+    Pack<T> o;
+#pragma unroll
+    for (int e = 0; e < S::N; ++e) {
+      const T w = (e == 0) ? left : mid.v[e - 1];
+      const T ea = (e == S::N - 1) ? right : mid.v[e + 1];
+      const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
+      const T un = (f[k].v[e] + nb) * invD;
+      const T res = one_m_omega * mid.v[e] + omega * un;
+      const int gj = gj0 + e;
+      o.v[e] = (row_in && gj >= 1 && gj < g.ny - 1) ? res : mid.v[e];
+    }
+    if (gi < g.nx && gj0 < g.nyv) stg(out + (size_t)gi * g.ld + gj0, o);
+    up = mid;
+    mid = dn;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Red-black Gauss-Seidel, ONE colour per launch, in place (colour 0 = (i+j) even first).
+//   reference: solvers/smoothers.py:175-207; `poff` is the parity of the global index of local
+//   (0,0) so that a sub-domain keeps the global colouring.
+//   Same-colour cells never neighbour each other, so in-place update within a launch is race free:
+//   a launch reads only the other colour (plus its own centre value) and writes only its colour.
+// --------------------------------------------------------------------------------------------
+template <typename T, int TAG>
+__global__ __launch_bounds__(kBlock) void rbgs_colour_kernel(T* __restrict__ u, const T* __restrict__ rhs, TileGeom g,
+                                                             T ihx2, T ihy2, T invD, T omega, T one_m_omega,
+                                                             int colour, int poff) {
+  using S = TileShape<T>;
+  __shared__ __attribute__((aligned(16))) T s[S::LDS_ELEMS];
+  const int L = xcd_remap(blockIdx.x, g.ntiles);
+  const int ti = L / g.tiles_j, tj = L - ti * g.tiles_j;
+  const int i0 = g.i_org + ti * kTI, j0 = tj * S::TJ;
+  const int cg = threadIdx.x % S::CG, rg = threadIdx.x / S::CG;
+  const int gj0 = j0 + cg * S::N;
+  const int lr = rg * S::RPT;
+
+  Pack<T> f[S::RPT];
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const int gi = i0 + lr + k;
+    f[k] = (gi < g.nx && gj0 < g.nyv) ? ldg(rhs + (size_t)gi * g.ld + gj0) : zero_pack<T>();
+  }
+  stage_tile<T>(u, s, i0, j0, g.nx, g.nyv, g.ld);
+  __syncthreads();
+
+  const int lc = S::N + cg * S::N;
+  Pack<T> up = *reinterpret_cast<const Pack<T>*>(s + (lr + 0) * S::SJ + lc);
+  Pack<T> mid = *reinterpret_cast<const Pack<T>*>(s + (lr + 1) * S::SJ + lc);
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const Pack<T> dn = *reinterpret_cast<const Pack<T>*>(s + (lr + k + 2) * S::SJ + lc);
+    const T left = s[(lr + k + 1) * S::SJ + lc - 1];
+    const T right = s[(lr + k + 1) * S::SJ + lc + S::N];
+    const int gi = i0 + lr + k;
+    const bool row_in = (gi >= 1) && (gi < g.nx - 1);
+    Pack<T> o;
+#pragma unroll
+    for (int e = 0; e < S::N; ++e) {
+      const T w = (e == 0) ? left : mid.v[e - 1];
+      const T ea = (e == S::N - 1) ? right : mid.v[e + 1];
+      const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
+      const T un = (f[k].v[e] + nb) * invD;
+      const T res = one_m_omega * mid.v[e] + omega * un;
+      const int gj = gj0 + e;
+      const bool mine = (((gi + gj + poff) & 1) == colour);
+      o.v[e] = (mine && row_in && gj >= 1 && gj < g.ny - 1) ? res : mid.v[e];
+    }
+    if (gi < g.nx && gj0 < g.nyv) stg(u + (size_t)gi * g.ld + gj0, o);
+    up = mid;
+    mid = dn;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Residual r = f - A u with A = coeff * (5-point Laplacian); boundary cells r = f.
+//   reference: operators/laplacian.py:73-77, 117-118:
+//     Au = coeff*(( (u[i+1]+u[i-1])/hx^2 + (u[j+1]+u[j-1])/hy^2 ) - u*(2/hx^2+2/hy^2))
+//   WRITE_R: store r (3 words/DoF) ; NORM: also emit one fp64 partial sum of r^2 per block
+//   (wave64 shuffle reduction, then 4 waves through LDS) -> ||r||^2 needs no second pass over r.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_reduce_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+
+// Sum over the block; result valid in thread 0.  `red` is >= 4 doubles of LDS.
+__device__ __forceinline__ double block_reduce_sum(double x, double* red) {
+  x = wave_reduce_sum(x);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) red[wid] = x;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+  }
+  return t;
+}
+
+template <typename T, bool WRITE_R, bool NORM, int TAG>
+__global__ __launch_bounds__(kBlock) void residual_kernel(const T* __restrict__ u, const T* __restrict__ rhs,
+                                                          T* __restrict__ r, double* __restrict__ partials, TileGeom g,
+                                                          T ihx2, T ihy2, T diag, T coeff) {
+  using S = TileShape<T>;
+  __shared__ __attribute__((aligned(16))) T s[S::LDS_ELEMS];
+  __shared__ double red[kBlock / 64];
+  const int L = xcd_remap(blockIdx.x, g.ntiles);
+  const int ti = L / g.tiles_j, tj = L - ti * g.tiles_j;
+  const int i0 = g.i_org + ti * kTI, j0 = tj * S::TJ;
+  const int cg = threadIdx.x % S::CG, rg = threadIdx.x / S::CG;
+  const int gj0 = j0 + cg * S::N;
+  const int lr = rg * S::RPT;
+
+  Pack<T> f[S::RPT];
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const int gi = i0 + lr + k;
+    f[k] = (gi < g.nx && gj0 < g.nyv) ? ldg(rhs + (size_t)gi * g.ld + gj0) : zero_pack<T>();
+  }
+  stage_tile<T>(u, s, i0, j0, g.nx, g.nyv, g.ld);
+  __syncthreads();
+
+  const int lc = S::N + cg * S::N;
+  Pack<T> up = *reinterpret_cast<const Pack<T>*>(s + (lr + 0) * S::SJ + lc);
+  Pack<T> mid = *reinterpret_cast<const Pack<T>*>(s + (lr + 1) * S::SJ + lc);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const Pack<T> dn = *reinterpret_cast<const Pack<T>*>(s + (lr + k + 2) * S::SJ + lc);
+    const T left = s[(lr + k + 1) * S::SJ + lc - 1];
+    const T right = s[(lr + k + 1) * S::SJ + lc + S::N];
+    const int gi = i0 + lr + k;
+    const bool row_in = (gi >= 1) && (gi < g.nx - 1);
+    Pack<T> o;
+#pragma unroll
+    for (int e = 0; e < S::N; ++e) {
+      const T w = (e == 0) ? left : mid.v[e - 1];
+      const T ea = (e == S::N - 1) ? right : mid.v[e + 1];
+      const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + w) * ihy2) - mid.v[e] * diag);
+      const int gj = gj0 + e;
+      const bool interior = row_in && gj >= 1 && gj < g.ny - 1;
+      const T rv = interior ? (f[k].v[e] - au) : f[k].v[e];
+      o.v[e] = rv;
+      if (NORM && gi < g.nx && gj < g.ny) acc += (double)rv * (double)rv;
+    }
+    if (WRITE_R && gi < g.nx && gj0 < g.ld) stg(r + (size_t)gi * g.ld + gj0, o);
+    up = mid;
+    mid = dn;
+  }
+  if (NORM) {
+    const double t = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
+// Plain sum of squares of a field (reference: core/grid.py:187 without the hx*hy factor and sqrt).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sumsq_kernel(const T* __restrict__ x, double* __restrict__ partials, int nx,
+                                                       int ny, int ld) {
+  constexpr int N = VecW<T>::N;
+  __shared__ double red[kBlock / 64];
+  const int vpr = (ny + N - 1) / N;
+  const long long total = (long long)nx * vpr;
+  double acc = 0.0;
+  for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
+    const int i = (int)(v / vpr), c = (int)(v - (long long)i * vpr);
+    const Pack<T> p = ldg(x + (size_t)i * ld + c * N);
+#pragma unroll
+    for (int e = 0; e < N; ++e)
+      if (c * N + e < ny) acc += (double)p.v[e] * (double)p.v[e];
+  }
+  const double t = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// Fixed-order final reduction of the per-block partials (deterministic, one block).
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials, int n,
+                                                                 double* __restrict__ out) {
+  __shared__ double red[kBlock / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += kBlock) acc += partials[i];
+  const double t = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) *out = t;
+}
+
+// --------------------------------------------------------------------------------------------
+// Full-weighting restriction, fine (nx,ny) -> coarse ((nx-1)/2+1, (ny-1)/2+1).
+//   reference: operators/transfer.py:100-124 -- interior:
+//     1/16*(((NW+NE)+SW)+SE) + 1/8*(((N+S)+W)+E) + 1/4*C   evaluated in the FIELD's dtype,
+//     result stored in the coarse grid's dtype; coarse boundary = injection.
+//   One thread produces one vector of coarse cells of one coarse row.
+// --------------------------------------------------------------------------------------------
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(kBlock) void restrict_fw_kernel(const TIN* __restrict__ fine, TOUT* __restrict__ coarse,
+                                                             int nxf, int nyf, int ldf, int nxc, int nyc, int ldc) {
+  constexpr int NO = VecW<TOUT>::N;
+  const int vpr = ldc / NO;
+  const long long total = (long long)nxc * vpr;
+  for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
+    const int ic = (int)(v / vpr), c = (int)(v - (long long)ic * vpr);
+    const int jc0 = c * NO;
+    const int fi = 2 * ic;
+    Pack<TOUT> o;
+#pragma unroll
+    for (int e = 0; e < NO; ++e) {
+      const int jc = jc0 + e, fj = 2 * jc;
+      TOUT val = TOUT(0);
+      if (jc < nyc) {
+        const TIN* p = fine + (size_t)fi * ldf + fj;
+        if (ic == 0 || ic == nxc - 1 || jc == 0 || jc == nyc - 1) {
+          val = (TOUT)p[0];
+        } else {
+          const TIN corners = ((p[-ldf - 1] + p[-ldf + 1]) + p[ldf - 1]) + p[ldf + 1];
+          const TIN edges = ((p[-ldf] + p[ldf]) + p[-1]) + p[1];
+          val = (TOUT)((TIN(1.0 / 16.0) * corners + TIN(1.0 / 8.0) * edges) + TIN(1.0 / 4.0) * p[0]);
+        }
+      }
+      o.v[e] = val;
+    }
+    stg(coarse + (size_t)ic * ldc + jc0, o);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Bilinear prolongation fused with the correction:  u += P e   (or u = P e when ADD == false).
+//   reference: operators/transfer.py:234-267 + solvers/multigrid.py:329.  Interpolation is evaluated
+//   in TC (the fine GRID's dtype in the reference), the sum u + Pe in the wider of (TF, TC), then
+//   rounded to TF -- NumPy's `u += fine_correction` semantics.
+//   Quirk F9 reproduced: (odd i, j == ny-1) and (i == nx-1, odd j) receive 0.
+// --------------------------------------------------------------------------------------------
+template <typename TC_IN, typename TF, typename TC, bool ADD>
+__global__ __launch_bounds__(kBlock) void prolong_kernel(const TC_IN* __restrict__ e, TF* __restrict__ u, int nxf,
+                                                         int nyf, int ldf, int ldc) {
+  constexpr int N = VecW<TF>::N;
+  using TS = typename std::conditional<(sizeof(TC) > sizeof(TF)), TC, TF>::type;
+  const int vpr = ldf / N;
+  const long long total = (long long)nxf * vpr;
+  for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
+    const int i = (int)(v / vpr), c = (int)(v - (long long)i * vpr);
+    const int j0 = c * N;
+    const int ic = i >> 1;
+    const bool iodd = i & 1;
+    const TC_IN* r0 = e + (size_t)ic * ldc;
+    const TC_IN* r1 = r0 + (iodd ? ldc : 0);
+    Pack<TF> uo = ADD ? ldg(u + (size_t)i * ldf + j0) : zero_pack<TF>();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int j = j0 + k;
+      if (j >= nyf) continue;
+      const int jc = j >> 1;
+      const bool jodd = j & 1;
+      TC val;
+      if (!iodd && !jodd) {
+        val = (TC)r0[jc];
+      } else if (iodd && !jodd) {
+        val = (j < nyf - 1) ? TC(0.5) * ((TC)r0[jc] + (TC)r1[jc]) : TC(0);
+      } else if (!iodd && jodd) {
+        val = (i < nxf - 1) ? TC(0.5) * ((TC)r0[jc] + (TC)r0[jc + 1]) : TC(0);
+      } else {
+        val = TC(0.25) * ((((TC)r0[jc] + (TC)r0[jc + 1]) + (TC)r1[jc]) + (TC)r1[jc + 1]);
+      }
+      uo.v[k] = ADD ? (TF)((TS)uo.v[k] + (TS)val) : (TF)val;
+    }
+    stg(u + (size_t)i * ldf + j0, uo);
+  }
+}
+
+// Element-wise precision switch (reference: core/precision.py:106-134 `astype`).
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(kBlock) void convert_kernel(const TIN* __restrict__ in, TOUT* __restrict__ out, int nx,
+                                                         int ny, int ldi, int ldo) {
+  const long long total = (long long)nx * ny;
+  for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
+    const int i = (int)(v / ny), j = (int)(v - (long long)i * ny);
+    out[(size_t)i * ldo + j] = (TOUT)in[(size_t)i * ldi + j];
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Coarsest-grid solver: lexicographic Gauss-Seidel sweeps until sqrt(hx*hy*sum r^2) < tol or maxit.
+//   reference: solvers/smoothers.py:153-173 driven by IterativeSolver.solve solvers/base.py:255-290
+//   (coarse_tolerance 1e-12, coarse_max_iterations 1000: solvers/multigrid.py:119-124).
+//   One workgroup.  Cells of one anti-diagonal i+j = s depend only on diagonal s-1 (already new) and
+//   s+1 (still old), so sweeping diagonals in order with a barrier in between reproduces the
+//   lexicographic loop bit for bit.  Every wave leaves through the same uniform exit test.
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u, const T* __restrict__ rhs, int nx,
+                                                              int ny, int ld, T ihx2, T ihy2, T invD, T omega,
+                                                              T one_m_omega, T diag, T coeff, double hxhy, double tol,
+                                                              int maxit, int* __restrict__ sweeps_out) {
+  __shared__ double red[kBlock / 64];
+  __shared__ double total;
+  int it = 0;
+  for (it = 1; it <= maxit; ++it) {
+    for (int sdiag = 2; sdiag <= nx + ny - 4; ++sdiag) {
+      const int ilo = max(1, sdiag - (ny - 2)), ihi = min(nx - 2, sdiag - 1);
+      for (int i = ilo + (int)threadIdx.x; i <= ihi; i += kBlock) {
+        const int j = sdiag - i;
+        T* p = u + (size_t)i * ld + j;
+        const T nb = ihx2 * (p[ld] + p[-ld]) + ihy2 * (p[1] + p[-1]);
+        const T un = (rhs[(size_t)i * ld + j] + nb) * invD;
+        p[0] = one_m_omega * p[0] + omega * un;
+      }
+      __syncthreads();
+    }
+    double acc = 0.0;
+    for (int idx = threadIdx.x; idx < nx * ny; idx += kBlock) {
+      const int i = idx / ny, j = idx - i * ny;
+      const T* p = u + (size_t)i * ld + j;
+      T rv = rhs[(size_t)i * ld + j];
+      if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1)
+        rv = rv - coeff * (((p[ld] + p[-ld]) * ihx2 + (p[1] + p[-1]) * ihy2) - p[0] * diag);
+      acc += (double)rv * (double)rv;
+    }
+    const double t = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) total = t;
+    __syncthreads();
+    const bool done = sqrt(hxhy * total) < tol;
+    __syncthreads();
+    if (done) break;
+  }
+  if (threadIdx.x == 0 && sweeps_out) *sweeps_out = (it > maxit) ? maxit : it;
+}
+
+}  // namespace mg

@@ -1,0 +1,990 @@
+// libmghip.so -- C ABI (include/mghip.h) over the CDNA4 kernels in mg_kernels.hpp, plus the
+// device-resident V/W/F-cycle driver (reference: solvers/multigrid.py:184-337, gpu/gpu_solver.py:186-446).
+// No Python, no torch types: plain pointers and sizes.
+#include "mg_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mghip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int fail(std::string* where, int code, const std::string& msg) {
+  g_last_error = msg;
+  if (where) *where = msg;
+  return code;
+}
+
+#define HIPC(errstr, call)                                                                         \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(errstr, (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? MG_ERR_NO_DEVICE : \
+                          (e_ == hipErrorOutOfMemory ? MG_ERR_ALLOC : MG_ERR_HIP),                 \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                              \
+  } while (0)
+
+inline size_t esize(int dt) { return dt == MG_F32 ? 4 : 8; }
+inline bool valid_dtype(int dt) { return dt == MG_F32 || dt == MG_F64; }
+
+// Row pitch in elements: rows start on 512-byte boundaries (every tile row segment is line aligned).
+inline int pitch_elems(int dt, int ny) {
+  const size_t bytes = ((size_t)ny * esize(dt) + 511) / 512 * 512;
+  return (int)(bytes / esize(dt));
+}
+
+constexpr int kMaxPartials = 1 << 16;   // upper bound on blocks that emit a partial sum
+
+template <typename T>
+mg::TileGeom make_geom(int nx, int ny, int ld, bool interior_only) {
+  using S = mg::TileShape<T>;
+  mg::TileGeom g;
+  g.nx = nx; g.ny = ny; g.ld = ld;
+  g.nyv = std::min(ld, (ny + S::N - 1) / S::N * S::N);
+  g.i_org = interior_only ? 1 : 0;
+  const int rows = interior_only ? nx - 2 : nx;
+  const int cols = interior_only ? ny - 1 : ny;     // column ny-1 is boundary: never written by a smoother
+  const int tiles_i = (rows + mg::kTI - 1) / mg::kTI;
+  g.tiles_j = (cols + S::TJ - 1) / S::TJ;
+  g.ntiles = tiles_i * g.tiles_j;
+  return g;
+}
+
+struct Coef {
+  double ihx2, ihy2, diag, invD;
+};
+inline Coef coefs(double hx, double hy) {
+  Coef c;
+  c.ihx2 = 1.0 / (hx * hx);
+  c.ihy2 = 1.0 / (hy * hy);
+  c.diag = 2.0 / (hx * hx) + 2.0 / (hy * hy);   // operators/laplacian.py:76, smoothers.py:65
+  c.invD = 1.0 / c.diag;
+  return c;
+}
+
+inline int grid_for(long long work_items) {
+  long long b = (work_items + mg::kBlock - 1) / mg::kBlock;
+  return (int)std::max<long long>(1, std::min<long long>(b, 256 * 16));
+}
+
+// ------------------------------------------------------------------ typed launchers ------------
+template <typename T>
+void launch_jacobi(const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy,
+                   double omega, hipStream_t st, bool fine = false) {
+  if (nx < 3 || ny < 3) return;
+  const Coef c = coefs(hx, hy);
+  const mg::TileGeom g = make_geom<T>(nx, ny, ld, true);
+  auto k = fine ? mg::jacobi_kernel<T, mg::kFineTag> : mg::jacobi_kernel<T, mg::kCoarseTag>;
+  hipLaunchKernelGGL(k, dim3(g.ntiles), dim3(mg::kBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out,
+                     g, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)omega, (T)(1.0 - omega));
+}
+
+template <typename T>
+void launch_rbgs_colour(void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double omega,
+                        int colour, int poff, hipStream_t st, bool fine = false) {
+  if (nx < 3 || ny < 3) return;
+  const Coef c = coefs(hx, hy);
+  const mg::TileGeom g = make_geom<T>(nx, ny, ld, true);
+  auto k = fine ? mg::rbgs_colour_kernel<T, mg::kFineTag> : mg::rbgs_colour_kernel<T, mg::kCoarseTag>;
+  hipLaunchKernelGGL(k, dim3(g.ntiles), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, g,
+                     (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)omega, (T)(1.0 - omega), colour, poff & 1);
+}
+
+// returns the number of partials written (0 when NORM is off)
+template <typename T, bool WRITE_R, bool NORM>
+int launch_residual(const void* u, const void* f, void* r, double* partials, int nx, int ny, int ld, double hx,
+                    double hy, double coeff, hipStream_t st, bool fine = false) {
+  const Coef c = coefs(hx, hy);
+  const mg::TileGeom g = make_geom<T>(nx, ny, ld, false);
+  auto k = fine ? mg::residual_kernel<T, WRITE_R, NORM, mg::kFineTag> : mg::residual_kernel<T, WRITE_R, NORM, mg::kCoarseTag>;
+  hipLaunchKernelGGL(k, dim3(g.ntiles), dim3(mg::kBlock), 0, st, (const T*)u,
+                     (const T*)f, (T*)r, partials, g, (T)c.ihx2, (T)c.ihy2, (T)c.diag, (T)coeff);
+  return NORM ? g.ntiles : 0;
+}
+
+template <typename T>
+int launch_sumsq(const void* x, double* partials, int nx, int ny, int ld, hipStream_t st) {
+  const int N = mg::VecW<T>::N;
+  const int nb = std::min(grid_for((long long)nx * ((ny + N - 1) / N)), 2048);
+  hipLaunchKernelGGL(mg::sumsq_kernel<T>, dim3(nb), dim3(mg::kBlock), 0, st, (const T*)x, partials, nx, ny, ld);
+  return nb;
+}
+
+inline void launch_reduce(const double* partials, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(mg::reduce_partials_kernel, dim3(1), dim3(mg::kBlock), 0, st, partials, n, out);
+}
+
+template <typename TI, typename TO>
+void launch_restrict(const void* fine, void* coarse, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
+  const int nxc = (nxf - 1) / 2 + 1, nyc = (nyf - 1) / 2 + 1;
+  const int NO = mg::VecW<TO>::N;
+  hipLaunchKernelGGL((mg::restrict_fw_kernel<TI, TO>), dim3(grid_for((long long)nxc * (ldc / NO))), dim3(mg::kBlock), 0,
+                     st, (const TI*)fine, (TO*)coarse, nxf, nyf, ldf, nxc, nyc, ldc);
+}
+
+template <typename TCI, typename TF, typename TC, bool ADD>
+void launch_prolong(const void* e, void* u, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
+  const int N = mg::VecW<TF>::N;
+  hipLaunchKernelGGL((mg::prolong_kernel<TCI, TF, TC, ADD>), dim3(grid_for((long long)nxf * (ldf / N))),
+                     dim3(mg::kBlock), 0, st, (const TCI*)e, (TF*)u, nxf, nyf, ldf, ldc);
+}
+
+template <typename TI, typename TO>
+void launch_convert(const void* in, void* out, int nx, int ny, int ldi, int ldo, hipStream_t st) {
+  hipLaunchKernelGGL((mg::convert_kernel<TI, TO>), dim3(grid_for((long long)nx * ny)), dim3(mg::kBlock), 0, st,
+                     (const TI*)in, (TO*)out, nx, ny, ldi, ldo);
+}
+
+template <typename T>
+void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff, double omega,
+                   double tol, int maxit, int* sweeps_dev, hipStream_t st) {
+  const Coef c = coefs(hx, hy);
+  hipLaunchKernelGGL(mg::coarse_lexgs_kernel<T>, dim3(1), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
+                     (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol,
+                     maxit, sweeps_dev);
+}
+
+// ------------------------------------------------------------------ dtype dispatch --------------
+void d_jacobi(int dt, const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy,
+              double omega, hipStream_t st, bool fine = false) {
+  if (dt == MG_F32) launch_jacobi<float>(u, rhs, out, nx, ny, ld, hx, hy, omega, st, fine);
+  else launch_jacobi<double>(u, rhs, out, nx, ny, ld, hx, hy, omega, st, fine);
+}
+void d_rbgs_colour(int dt, void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double omega,
+                   int colour, int poff, hipStream_t st, bool fine = false) {
+  if (dt == MG_F32) launch_rbgs_colour<float>(u, rhs, nx, ny, ld, hx, hy, omega, colour, poff, st, fine);
+  else launch_rbgs_colour<double>(u, rhs, nx, ny, ld, hx, hy, omega, colour, poff, st, fine);
+}
+void d_residual(int dt, const void* u, const void* f, void* r, int nx, int ny, int ld, double hx, double hy,
+                double coeff, hipStream_t st, bool fine = false) {
+  if (dt == MG_F32) launch_residual<float, true, false>(u, f, r, nullptr, nx, ny, ld, hx, hy, coeff, st, fine);
+  else launch_residual<double, true, false>(u, f, r, nullptr, nx, ny, ld, hx, hy, coeff, st, fine);
+}
+int d_residual_norm(int dt, const void* u, const void* f, double* partials, int nx, int ny, int ld, double hx,
+                    double hy, double coeff, hipStream_t st, bool fine = false) {
+  if (dt == MG_F32) return launch_residual<float, false, true>(u, f, nullptr, partials, nx, ny, ld, hx, hy, coeff, st, fine);
+  return launch_residual<double, false, true>(u, f, nullptr, partials, nx, ny, ld, hx, hy, coeff, st, fine);
+}
+int d_sumsq(int dt, const void* x, double* partials, int nx, int ny, int ld, hipStream_t st) {
+  return dt == MG_F32 ? launch_sumsq<float>(x, partials, nx, ny, ld, st) : launch_sumsq<double>(x, partials, nx, ny, ld, st);
+}
+void d_restrict(int di, int dout, const void* fine, void* coarse, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
+  if (di == MG_F32 && dout == MG_F32) launch_restrict<float, float>(fine, coarse, nxf, nyf, ldf, ldc, st);
+  else if (di == MG_F64 && dout == MG_F64) launch_restrict<double, double>(fine, coarse, nxf, nyf, ldf, ldc, st);
+  else if (di == MG_F64 && dout == MG_F32) launch_restrict<double, float>(fine, coarse, nxf, nyf, ldf, ldc, st);
+  else launch_restrict<float, double>(fine, coarse, nxf, nyf, ldf, ldc, st);
+}
+// dc: dtype of the coarse field, df: of the fine field, dcomp: interpolation arithmetic (the fine GRID's dtype)
+template <bool ADD>
+int d_prolong(int dc, int df, int dcomp, const void* e, void* u, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
+  if (dcomp == MG_F32) {
+    if (dc == MG_F32 && df == MG_F32) { launch_prolong<float, float, float, ADD>(e, u, nxf, nyf, ldf, ldc, st); return MG_OK; }
+    return MG_ERR_INVALID_VALUE;   // fp32 interpolation only exists for an all-fp32 grid
+  }
+  if (dc == MG_F64 && df == MG_F64) launch_prolong<double, double, double, ADD>(e, u, nxf, nyf, ldf, ldc, st);
+  else if (dc == MG_F32 && df == MG_F64) launch_prolong<float, double, double, ADD>(e, u, nxf, nyf, ldf, ldc, st);
+  else if (dc == MG_F64 && df == MG_F32) launch_prolong<double, float, double, ADD>(e, u, nxf, nyf, ldf, ldc, st);
+  else launch_prolong<float, float, double, ADD>(e, u, nxf, nyf, ldf, ldc, st);
+  return MG_OK;
+}
+void d_convert(int di, int dout, const void* in, void* out, int nx, int ny, int ldi, int ldo, hipStream_t st) {
+  if (di == MG_F32 && dout == MG_F32) launch_convert<float, float>(in, out, nx, ny, ldi, ldo, st);
+  else if (di == MG_F64 && dout == MG_F64) launch_convert<double, double>(in, out, nx, ny, ldi, ldo, st);
+  else if (di == MG_F64 && dout == MG_F32) launch_convert<double, float>(in, out, nx, ny, ldi, ldo, st);
+  else launch_convert<float, double>(in, out, nx, ny, ldi, ldo, st);
+}
+void d_coarse(int dt, void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff,
+              double omega, double tol, int maxit, int* sweeps_dev, hipStream_t st) {
+  if (dt == MG_F32) launch_coarse<float>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st);
+  else launch_coarse<double>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st);
+}
+
+// ------------------------------------------------------------------ host <-> device helpers -----
+int upload(std::string* err, void* dev, int ddt, int ld, const void* host, int hdt, int nx, int ny, void* staging,
+           hipStream_t st) {
+  if (ddt == hdt) {
+    HIPC(err, hipMemcpy2DAsync(dev, (size_t)ld * esize(ddt), host, (size_t)ny * esize(hdt), (size_t)ny * esize(hdt), nx,
+                               hipMemcpyHostToDevice, st));
+  } else {   // upload in the host dtype into staging (pitch = ld of the HOST dtype), then cast on the device
+    const int lds = pitch_elems(hdt, ny);
+    HIPC(err, hipMemcpy2DAsync(staging, (size_t)lds * esize(hdt), host, (size_t)ny * esize(hdt), (size_t)ny * esize(hdt),
+                               nx, hipMemcpyHostToDevice, st));
+    d_convert(hdt, ddt, staging, dev, nx, ny, lds, ld, st);
+  }
+  HIPC(err, hipStreamSynchronize(st));
+  return MG_OK;
+}
+
+int download(std::string* err, void* host, int hdt, const void* dev, int ddt, int ld, int nx, int ny, void* staging,
+             hipStream_t st) {
+  if (ddt == hdt) {
+    HIPC(err, hipMemcpy2DAsync(host, (size_t)ny * esize(hdt), dev, (size_t)ld * esize(ddt), (size_t)ny * esize(hdt), nx,
+                               hipMemcpyDeviceToHost, st));
+  } else {
+    const int lds = pitch_elems(hdt, ny);
+    d_convert(ddt, hdt, dev, staging, nx, ny, ld, lds, st);
+    HIPC(err, hipMemcpy2DAsync(host, (size_t)ny * esize(hdt), staging, (size_t)lds * esize(hdt), (size_t)ny * esize(hdt),
+                               nx, hipMemcpyDeviceToHost, st));
+  }
+  HIPC(err, hipStreamSynchronize(st));
+  return MG_OK;
+}
+
+struct Level {
+  int nx = 0, ny = 0;
+  double hx = 0, hy = 0;
+  int ld[2] = {0, 0};
+  void* u[2] = {nullptr, nullptr};     // current iterate
+  void* t[2] = {nullptr, nullptr};     // Jacobi ping-pong partner (same boundary ring as u)
+  void* rhs[2] = {nullptr, nullptr};
+  void* r[2] = {nullptr, nullptr};     // residual
+  double timings[3] = {0, 0, 0};       // smooth / restrict / prolong seconds (cfg.profile)
+};
+
+}  // namespace
+
+struct mg_handle {
+  mg_config cfg;
+  std::vector<Level> lv;
+  hipStream_t stream = nullptr;
+  double* partials = nullptr;   // device, kMaxPartials doubles
+  double* d_scalar = nullptr;   // device, one double
+  int* d_int = nullptr;         // device, one int (coarse sweeps)
+  double* h_scalar = nullptr;   // pinned host
+  int* h_int = nullptr;         // pinned host
+  void* staging = nullptr;      // fine-level sized fp64 staging for dtype-converting transfers
+  int grid_dtype = MG_F64;      // the reference Grid's dtype: MG_F32 only for MG_PREC_SINGLE
+  int phase = MG_F64;           // working precision of the adaptive policy
+  bool promoted = false;        // one-way rule: fp32 -> fp64 happened
+  bool have_rhs = false;
+  std::string err;
+  std::vector<double> adapt_hist;
+
+  int L() const { return (int)lv.size(); }
+  // precision a level computes in (solvers/multigrid.py:275-285 + core/precision.py:337-357); the coarsest
+  // level is never converted by the reference (multigrid.py:270-272 returns first) and stays in the grid dtype.
+  int level_dtype(int l) const {
+    if (l == L() - 1) return grid_dtype;
+    switch (cfg.precision) {
+      case MG_PREC_SINGLE: return MG_F32;
+      case MG_PREC_MIXED_LEVELS: return (l >= L() / 2) ? MG_F32 : MG_F64;
+      case MG_PREC_ADAPTIVE: return phase;
+      default: return MG_F64;
+    }
+  }
+  bool needs(int l, int dt) const {
+    if (cfg.precision == MG_PREC_ADAPTIVE) return (l == L() - 1) ? dt == grid_dtype : true;
+    return level_dtype(l) == dt;
+  }
+};
+
+namespace {
+
+int alloc_zero(std::string* err, void** p, size_t bytes) {
+  HIPC(err, hipMalloc(p, bytes));
+  HIPC(err, hipMemset(*p, 0, bytes));
+  return MG_OK;
+}
+
+void release(mg_handle* h) {
+  for (auto& l : h->lv)
+    for (int d = 0; d < 2; ++d) {
+      if (l.u[d]) (void)hipFree(l.u[d]);
+      if (l.t[d]) (void)hipFree(l.t[d]);
+      if (l.rhs[d]) (void)hipFree(l.rhs[d]);
+      if (l.r[d]) (void)hipFree(l.r[d]);
+    }
+  if (h->partials) (void)hipFree(h->partials);
+  if (h->d_scalar) (void)hipFree(h->d_scalar);
+  if (h->d_int) (void)hipFree(h->d_int);
+  if (h->staging) (void)hipFree(h->staging);
+  if (h->h_scalar) (void)hipHostFree(h->h_scalar);
+  if (h->h_int) (void)hipHostFree(h->h_int);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+// ---- the cycle -----------------------------------------------------------------------------
+struct StageTimer {
+  mg_handle* h; Level* lv; int slot; double t0 = 0;
+  StageTimer(mg_handle* h_, Level* lv_, int slot_) : h(h_), lv(lv_), slot(slot_) {
+    if (h->cfg.profile) { (void)hipStreamSynchronize(h->stream); t0 = now_s(); }
+  }
+  ~StageTimer() {
+    if (h->cfg.profile) { (void)hipStreamSynchronize(h->stream); lv->timings[slot] += now_s() - t0; }
+  }
+};
+
+void smooth(mg_handle* h, int l, int nu) {
+  Level& v = h->lv[l];
+  const int dt = h->level_dtype(l);
+  StageTimer tm(h, &v, 0);
+  for (int s = 0; s < nu; ++s) {
+    if (h->cfg.smoother == MG_JACOBI) {
+      d_jacobi(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, l == 0);
+      std::swap(v.u[dt], v.t[dt]);
+    } else if (h->cfg.smoother == MG_RBGS) {
+      for (int colour = 0; colour < 2; ++colour)
+        d_rbgs_colour(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, colour,
+                      h->cfg.colour_offset, h->stream, l == 0);
+    } else {   // MG_LEXGS: exactly `nu` sweeps (tol < 0 never triggers the early exit)
+      d_coarse(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, h->cfg.omega, -1.0, nu - s,
+               nullptr, h->stream);
+      break;
+    }
+  }
+}
+
+void coarse_solve(mg_handle* h, int l) {
+  Level& v = h->lv[l];
+  const int dt = h->level_dtype(l);
+  // solvers/multigrid.py:119-124: the default coarse solver is GaussSeidelSmoother(omega = 1)
+  d_coarse(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, 1.0, h->cfg.coarse_tol,
+           h->cfg.coarse_maxit, h->d_int, h->stream);
+}
+
+int cycle(mg_handle* h, int l) {
+  const int L = h->L();
+  if (l == L - 1) { coarse_solve(h, l); return MG_OK; }
+  Level& f = h->lv[l];
+  Level& c = h->lv[l + 1];
+  const int dt = h->level_dtype(l), dc = h->level_dtype(l + 1);
+  if (h->cfg.pre > 0) smooth(h, l, h->cfg.pre);
+  {
+    StageTimer tm(h, &f, 1);
+    d_residual(dt, f.u[dt], f.rhs[dt], f.r[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.coeff, h->stream, l == 0);
+    d_restrict(dt, dc, f.r[dt], c.rhs[dc], f.nx, f.ny, f.ld[dt], c.ld[dc], h->stream);
+  }
+  (void)hipMemsetAsync(c.u[dc], 0, (size_t)c.nx * c.ld[dc] * esize(dc), h->stream);
+  int reps = 1;
+  if (h->cfg.cycle == MG_CYCLE_W) reps = 2;
+  else if (h->cfg.cycle == MG_CYCLE_F) reps = std::max(1, 1 << std::max(0, L - l - 2));   // multigrid.py:315-319
+  for (int k = 0; k < reps; ++k) {
+    const int rc = cycle(h, l + 1);
+    if (rc != MG_OK) return rc;
+  }
+  {
+    StageTimer tm(h, &f, 2);
+    const int rc = d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], f.u[dt], f.nx, f.ny, f.ld[dt], c.ld[dc], h->stream);
+    if (rc != MG_OK) return rc;
+  }
+  if (h->cfg.post > 0) smooth(h, l, h->cfg.post);
+  return MG_OK;
+}
+
+int fine_norm(mg_handle* h, double* out) {
+  Level& v = h->lv[0];
+  const int dt = h->level_dtype(0);
+  const int n = d_residual_norm(dt, v.u[dt], v.rhs[dt], h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff,
+                                h->stream, true);
+  launch_reduce(h->partials, n, h->d_scalar, h->stream);
+  HIPC(&h->err, hipMemcpyAsync(h->h_scalar, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPC(&h->err, hipStreamSynchronize(h->stream));
+  *out = std::sqrt(v.hx * v.hy * *h->h_scalar);
+  return MG_OK;
+}
+
+// in-device cast of the fine iterate when the adaptive policy changes the working precision
+int switch_phase(mg_handle* h, int to) {
+  if (h->cfg.precision != MG_PREC_ADAPTIVE || to == h->phase) return MG_OK;
+  Level& v = h->lv[0];
+  const int from = h->phase;
+  if (h->L() > 1) {   // with a single level the only level is the coarsest and lives in the grid dtype
+    d_convert(from, to, v.u[from], v.u[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
+    if (v.t[to]) d_convert(from, to, v.u[from], v.t[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
+  }
+  h->phase = to;
+  return MG_OK;
+}
+
+// core/precision.py:189-246 should_promote_precision, on the last five residual norms
+bool stagnating(const std::vector<double>& hist) {
+  if (hist.size() < 5) return false;
+  const double* r = hist.data() + hist.size() - 5;
+  double sum = 0; int n = 0;
+  for (int i = 1; i < 5; ++i) if (r[i - 1] > 0) { sum += r[i] / r[i - 1]; ++n; }
+  if (n) {
+    if (sum / n > 0.9) return true;
+    double rel = 0; int m = 0;
+    for (int i = 1; i < 5; ++i) if (r[i - 1] > 0) { rel += std::fabs(r[i] - r[i - 1]) / r[i - 1]; ++m; }
+    if (m && rel / m < 1e-3) return true;
+  }
+  bool inc = true;
+  for (int i = 1; i < 5; ++i) inc = inc && (r[i] >= r[i - 1] * 0.99);
+  return inc;
+}
+
+// core/precision.py:270-302 update_precision (+ the one-way variant documented in mghip.h)
+int adapt(mg_handle* h, double rn) {
+  if (h->cfg.precision != MG_PREC_ADAPTIVE) return MG_OK;
+  const double thr = h->cfg.switch_threshold;
+  double pts = 0;
+  for (auto& l : h->lv) pts += (double)l.nx * l.ny;
+  const double mem = pts * esize(h->phase) * 4.0;                       // precision.py:136-153
+  const bool mem_down = mem > h->cfg.memory_threshold_gb * 1024.0 * 1024.0 * 1024.0;
+  int to = h->phase;
+  if (h->cfg.adaptive_reference_rule) {
+    if (mem_down || (h->phase == MG_F64 && rn > thr * 100)) { if (h->phase == MG_F64) to = MG_F32; }
+    else if (h->phase == MG_F32 && rn < thr * 10) to = MG_F64;
+  } else if (!h->promoted) {
+    if (h->phase == MG_F64 && (mem_down || rn > thr * 100) && h->adapt_hist.empty()) to = MG_F32;
+    else if (h->phase == MG_F32 && (rn < thr * 10 || stagnating(h->adapt_hist))) { to = MG_F64; h->promoted = true; }
+  }
+  return switch_phase(h, to);
+}
+
+int set_rhs_impl(mg_handle* h, const void* rhs, int hdt) {
+  Level& v = h->lv[0];
+  for (int dt = 0; dt < 2; ++dt)
+    if (v.rhs[dt]) {
+      const int rc = upload(&h->err, v.rhs[dt], dt, v.ld[dt], rhs, hdt, v.nx, v.ny, h->staging, h->stream);
+      if (rc != MG_OK) return rc;
+    }
+  h->have_rhs = true;
+  return MG_OK;
+}
+
+int set_u_impl(mg_handle* h, const void* u0, int hdt) {
+  Level& v = h->lv[0];
+  const int dt = h->level_dtype(0);
+  if (u0) {
+    int rc = upload(&h->err, v.u[dt], dt, v.ld[dt], u0, hdt, v.nx, v.ny, h->staging, h->stream);
+    if (rc != MG_OK) return rc;
+    if (v.t[dt]) {   // the ping-pong partner must carry the same boundary ring
+      HIPC(&h->err, hipMemcpyAsync(v.t[dt], v.u[dt], (size_t)v.nx * v.ld[dt] * esize(dt), hipMemcpyDeviceToDevice, h->stream));
+    }
+  } else {
+    HIPC(&h->err, hipMemsetAsync(v.u[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
+    if (v.t[dt]) HIPC(&h->err, hipMemsetAsync(v.t[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
+  }
+  HIPC(&h->err, hipStreamSynchronize(h->stream));
+  return MG_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI =====================
+extern "C" {
+
+const char* mg_version(void) { return "mghip 0.1 (gfx950)"; }
+
+int mg_device_count(int* count) {
+  if (!count) return fail(nullptr, MG_ERR_INVALID_VALUE, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(nullptr, MG_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  *count = n;
+  return MG_OK;
+}
+
+const char* mg_last_error(const mg_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int mg_pitch_elems(int dtype, int ny, int* ld) {
+  if (!valid_dtype(dtype) || ny < 1 || !ld) return fail(nullptr, MG_ERR_INVALID_VALUE, "mg_pitch_elems: bad argument");
+  *ld = pitch_elems(dtype, ny);
+  return MG_OK;
+}
+
+int mg_create(const mg_config* cfg, mg_handle** out) {
+  if (!cfg || !out) return fail(nullptr, MG_ERR_INVALID_VALUE, "mg_create: NULL argument");
+  *out = nullptr;
+  if (cfg->nx < 3 || cfg->ny < 3)
+    return fail(nullptr, MG_ERR_INVALID_VALUE, "Grid must have at least 3 points in each direction");   // core/grid.py:34-35
+  if (cfg->cycle < MG_CYCLE_V || cfg->cycle > MG_CYCLE_F) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown cycle type");
+  if (cfg->smoother < MG_JACOBI || cfg->smoother > MG_LEXGS) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown smoother");
+  if (cfg->precision < MG_PREC_DOUBLE || cfg->precision > MG_PREC_ADAPTIVE) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown precision policy");
+  if (cfg->pre < 0 || cfg->post < 0 || cfg->max_levels < 1 || cfg->coarse_maxit < 1)
+    return fail(nullptr, MG_ERR_INVALID_VALUE, "negative sweep count / max_levels < 1 / coarse_maxit < 1");
+  if (!(cfg->x1 > cfg->x0) || !(cfg->y1 > cfg->y0)) return fail(nullptr, MG_ERR_INVALID_VALUE, "empty domain");
+
+  int ndev = 0;
+  int rc = mg_device_count(&ndev);
+  if (rc != MG_OK) return rc;
+  if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MG_ERR_NO_DEVICE, "no such HIP device");
+  HIPC(nullptr, hipSetDevice(cfg->device));
+
+  mg_handle* h = new mg_handle();
+  h->cfg = *cfg;
+  h->grid_dtype = (cfg->precision == MG_PREC_SINGLE) ? MG_F32 : MG_F64;
+  h->phase = MG_F64;
+  // hierarchy: solvers/multigrid.py:135-171
+  int nx = cfg->nx, ny = cfg->ny;
+  for (int level = 0; level < cfg->max_levels; ++level) {
+    if (level > 0) {
+      if ((nx - 1) % 2 != 0 || (ny - 1) % 2 != 0) break;          // core/grid.py:148-149
+      const int cx = (nx - 1) / 2 + 1, cy = (ny - 1) / 2 + 1;
+      if (cx < 5 || cy < 5) break;                                 // multigrid.py:158-160
+      nx = cx; ny = cy;
+    }
+    Level l;
+    l.nx = nx; l.ny = ny;
+    l.hx = (cfg->x1 - cfg->x0) / (nx - 1);
+    l.hy = (cfg->y1 - cfg->y0) / (ny - 1);
+    l.ld[0] = pitch_elems(MG_F32, ny);
+    l.ld[1] = pitch_elems(MG_F64, ny);
+    h->lv.push_back(l);
+  }
+  auto bail = [&](int code) { release(h); std::string m = h->err; delete h; g_last_error = m; return code; };
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(MG_ERR_HIP); }
+  for (int l = 0; l < h->L(); ++l) {
+    Level& v = h->lv[l];
+    for (int dt = 0; dt < 2; ++dt) {
+      if (!h->needs(l, dt)) continue;
+      const size_t bytes = (size_t)v.nx * v.ld[dt] * esize(dt);
+      if ((rc = alloc_zero(&h->err, &v.u[dt], bytes)) != MG_OK) return bail(rc);
+      if ((rc = alloc_zero(&h->err, &v.rhs[dt], bytes)) != MG_OK) return bail(rc);
+      if (l < h->L() - 1) {
+        if ((rc = alloc_zero(&h->err, &v.r[dt], bytes)) != MG_OK) return bail(rc);
+        if (cfg->smoother == MG_JACOBI && (rc = alloc_zero(&h->err, &v.t[dt], bytes)) != MG_OK) return bail(rc);
+      }
+    }
+  }
+  if ((rc = alloc_zero(&h->err, (void**)&h->partials, sizeof(double) * kMaxPartials)) != MG_OK) return bail(rc);
+  if ((rc = alloc_zero(&h->err, (void**)&h->d_scalar, sizeof(double))) != MG_OK) return bail(rc);
+  if ((rc = alloc_zero(&h->err, (void**)&h->d_int, sizeof(int))) != MG_OK) return bail(rc);
+  if ((rc = alloc_zero(&h->err, &h->staging, (size_t)cfg->nx * pitch_elems(MG_F64, cfg->ny) * 8)) != MG_OK) return bail(rc);
+  if (hipHostMalloc((void**)&h->h_scalar, sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_int, sizeof(int)) != hipSuccess) { h->err = "hipHostMalloc failed"; return bail(MG_ERR_ALLOC); }
+  {
+    const mg::TileGeom g = make_geom<double>(cfg->nx, cfg->ny, h->lv[0].ld[1], false);
+    if (g.ntiles > kMaxPartials) { h->err = "grid too large for the partial-sum buffer"; return bail(MG_ERR_INVALID_VALUE); }
+  }
+  *out = h;
+  return MG_OK;
+}
+
+int mg_destroy(mg_handle* h) {
+  if (!h) return MG_OK;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  release(h);
+  delete h;
+  return MG_OK;
+}
+
+int mg_num_levels(const mg_handle* h, int* n) {
+  if (!h || !n) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL argument");
+  *n = h->L();
+  return MG_OK;
+}
+
+int mg_level_shape(const mg_handle* h, int level, int* nx, int* ny) {
+  if (!h || !nx || !ny || level < 0 || level >= h->L()) return fail(nullptr, MG_ERR_INVALID_VALUE, "bad level");
+  *nx = h->lv[level].nx; *ny = h->lv[level].ny;
+  return MG_OK;
+}
+
+int mg_level_timings(const mg_handle* h, int level, double out3[3]) {
+  if (!h || !out3 || level < 0 || level >= h->L()) return fail(nullptr, MG_ERR_INVALID_VALUE, "bad level");
+  for (int k = 0; k < 3; ++k) out3[k] = h->lv[level].timings[k];
+  return MG_OK;
+}
+
+int mg_get_stream(mg_handle* h, void** stream) {
+  if (!h || !stream) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL argument");
+  *stream = (void*)h->stream;
+  return MG_OK;
+}
+
+int mg_synchronize(mg_handle* h) {
+  if (!h) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL handle");
+  HIPC(&h->err, hipStreamSynchronize(h->stream));
+  return MG_OK;
+}
+
+int mg_set_rhs(mg_handle* h, const void* rhs, int host_dtype) {
+  if (!h || !rhs || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_rhs: bad argument");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  return set_rhs_impl(h, rhs, host_dtype);
+}
+
+int mg_set_solution(mg_handle* h, const void* u0, int host_dtype) {
+  if (!h || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_solution: bad argument");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  return set_u_impl(h, u0, host_dtype);
+}
+
+int mg_get_solution(mg_handle* h, void* u_out, int host_dtype) {
+  if (!h || !u_out || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_get_solution: bad argument");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  Level& v = h->lv[0];
+  const int dt = h->level_dtype(0);
+  return download(&h->err, u_out, host_dtype, v.u[dt], dt, v.ld[dt], v.nx, v.ny, h->staging, h->stream);
+}
+
+int mg_cycle(mg_handle* h, int ncycles) {
+  if (!h || ncycles < 0) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_cycle: bad argument");
+  if (!h->have_rhs) return fail(&h->err, MG_ERR_STATE, "mg_cycle before mg_set_rhs");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  for (int k = 0; k < ncycles; ++k) {
+    const int rc = cycle(h, 0);
+    if (rc != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+  }
+  HIPC(&h->err, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_residual_norm(mg_handle* h, double* out) {
+  if (!h || !out) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_residual_norm: bad argument");
+  if (!h->have_rhs) return fail(&h->err, MG_ERR_STATE, "mg_residual_norm before mg_set_rhs");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  return fine_norm(h, out);
+}
+
+int mg_set_working_precision(mg_handle* h, int dtype) {
+  if (!h || !valid_dtype(dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "bad argument");
+  if (h->cfg.precision != MG_PREC_ADAPTIVE) return fail(&h->err, MG_ERR_STATE, "working precision is fixed unless precision = MG_PREC_ADAPTIVE");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  return switch_phase(h, dtype);
+}
+
+static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, int hist_cap, int* n_iter,
+                        int* converged, int32_t* prec_hist, mg_stats* st) {
+  // reset the adaptive state (PrecisionManager starts every solve from default_precision = double)
+  if (h->cfg.precision == MG_PREC_ADAPTIVE) {
+    const int rc0 = switch_phase(h, MG_F64);
+    if (rc0 != MG_OK) return rc0;
+    h->promoted = false;
+    h->adapt_hist.clear();
+  }
+  for (auto& l : h->lv) l.timings[0] = l.timings[1] = l.timings[2] = 0;
+  const double t0 = now_s();
+  double rn = 0;
+  int rc = fine_norm(h, &rn);
+  if (rc != MG_OK) return rc;
+  st->initial_residual = rn;
+  int it = 0, conv = 0, switches = 0;
+  for (it = 1; it <= max_iter; ++it) {
+    const int before = h->phase;
+    if ((rc = adapt(h, rn)) != MG_OK) return rc;               // solvers/multigrid.py:224-227
+    if (h->phase != before) {
+      ++switches;
+      if (h->cfg.adaptive_reference_rule == 0) h->adapt_hist.clear();
+    }
+    if ((rc = cycle(h, 0)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+    if ((rc = fine_norm(h, &rn)) != MG_OK) return rc;         // multigrid.py:233
+    h->adapt_hist.push_back(rn);
+    if (it <= hist_cap) hist[it - 1] = rn;
+    if (prec_hist && it <= hist_cap)
+      prec_hist[it - 1] = (h->cfg.precision == MG_PREC_MIXED_LEVELS) ? 2 : h->level_dtype(0);
+    if (rn < tol) { conv = 1; break; }                         // solvers/base.py:134 (absolute)
+  }
+  if (it > max_iter) it = max_iter;
+  HIPC(&h->err, hipMemcpyAsync(h->h_int, h->d_int, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPC(&h->err, hipStreamSynchronize(h->stream));
+  st->last_coarse_sweeps = *h->h_int;
+  st->solve_seconds = now_s() - t0;
+  st->precision_switches = switches;
+  if (n_iter) *n_iter = it;
+  if (converged) *converged = conv;
+  return MG_OK;
+}
+
+int mg_iterate(mg_handle* h, double tol, int max_iter, double* hist, int hist_cap, int* n_iter, int* converged,
+               int32_t* prec_hist, mg_stats* stats) {
+  if (!h) return fail(nullptr, MG_ERR_STATE, "Multigrid not properly setup or grid mismatch");
+  if (max_iter < 1 || (hist_cap > 0 && !hist)) return fail(&h->err, MG_ERR_INVALID_VALUE, "mg_iterate: bad argument");
+  if (!h->have_rhs) return fail(&h->err, MG_ERR_STATE, "mg_iterate before mg_set_rhs");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  mg_stats st;
+  std::memset(&st, 0, sizeof(st));
+  const int rc = iterate_impl(h, tol, max_iter, hist, hist_cap, n_iter, converged, prec_hist, &st);
+  if (stats) *stats = st;
+  return rc;
+}
+
+int mg_solve(mg_handle* h, const void* rhs, const void* u0, void* u_out, int host_dtype, double tol, int max_iter,
+             double* hist, int hist_cap, int* n_iter, int* converged, int32_t* prec_hist, mg_stats* stats) {
+  if (!h) return fail(nullptr, MG_ERR_STATE, "Multigrid not properly setup or grid mismatch");
+  if (!rhs || !u_out || !valid_dtype(host_dtype) || max_iter < 1 || (hist_cap > 0 && !hist))
+    return fail(&h->err, MG_ERR_INVALID_VALUE, "mg_solve: bad argument");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  mg_stats st;
+  std::memset(&st, 0, sizeof(st));
+  if (h->cfg.precision == MG_PREC_ADAPTIVE) h->phase = MG_F64;   // upload into the fp64 iterate
+  double t0 = now_s();
+  int rc = set_rhs_impl(h, rhs, host_dtype);
+  if (rc != MG_OK) return rc;
+  rc = set_u_impl(h, u0, host_dtype);
+  if (rc != MG_OK) return rc;
+  st.h2d_seconds = now_s() - t0;
+  rc = iterate_impl(h, tol, max_iter, hist, hist_cap, n_iter, converged, prec_hist, &st);
+  if (rc != MG_OK) return rc;
+  t0 = now_s();
+  Level& v = h->lv[0];
+  const int dt = h->level_dtype(0);
+  rc = download(&h->err, u_out, host_dtype, v.u[dt], dt, v.ld[dt], v.nx, v.ny, h->staging, h->stream);
+  if (rc != MG_OK) return rc;
+  st.d2h_seconds = now_s() - t0;
+  if (stats) *stats = st;
+  return MG_OK;
+}
+
+int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg_ms) {
+  if (!h || !avg_ms || reps < 1 || level < 0 || level >= h->L() || !valid_dtype(dtype))
+    return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_time_op: bad argument");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  Level& v = h->lv[level];
+  const int dt = dtype;
+  if (op != 6 && (!v.u[dt] || !v.rhs[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: level has no arrays of that dtype");
+  if ((op == 0) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
+  if ((op == 2 || op == 4 || op == 5) && (level >= h->L() - 1 || !v.r[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no coarser level");
+  hipEvent_t e0, e1;
+  HIPC(&h->err, hipEventCreate(&e0));
+  HIPC(&h->err, hipEventCreate(&e1));
+  auto run = [&](int n) -> int {
+    for (int k = 0; k < n; ++k) {
+      switch (op) {
+        case 0: d_jacobi(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, level == 0);
+                std::swap(v.u[dt], v.t[dt]); break;
+        case 1: for (int c = 0; c < 2; ++c) d_rbgs_colour(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, c, h->cfg.colour_offset, h->stream, level == 0); break;
+        case 2: d_residual(dt, v.u[dt], v.rhs[dt], v.r[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, h->stream, level == 0); break;
+        case 3: { const int n2 = d_residual_norm(dt, v.u[dt], v.rhs[dt], h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, h->stream, level == 0);
+                  launch_reduce(h->partials, n2, h->d_scalar, h->stream); } break;
+        case 4: { Level& c = h->lv[level + 1]; const int dc = c.rhs[dt] ? dt : 1 - dt;
+                  d_restrict(dt, dc, v.r[dt], c.rhs[dc], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream); } break;
+        case 5: { Level& c = h->lv[level + 1]; const int dc = c.u[dt] ? dt : 1 - dt;
+                  if (d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], v.u[dt], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE; } break;
+        case 6: { const int rc = cycle(h, 0); if (rc != MG_OK) return rc; } break;
+        default: return MG_ERR_INVALID_VALUE;
+      }
+    }
+    return MG_OK;
+  };
+  int rc = run(1);   // warm-up
+  if (rc != MG_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(&h->err, rc, "mg_time_op: unsupported op"); }
+  HIPC(&h->err, hipEventRecord(e0, h->stream));
+  rc = run(reps);
+  HIPC(&h->err, hipEventRecord(e1, h->stream));
+  HIPC(&h->err, hipEventSynchronize(e1));
+  float ms = 0;
+  HIPC(&h->err, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *avg_ms = (double)ms / reps;
+  return rc;
+}
+
+// ---------------------------------------------------------------- stateless, device arrays ----
+#define CHECK_DEV(cond, msg) do { if (!(cond)) return fail(nullptr, MG_ERR_INVALID_VALUE, msg); } while (0)
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static bool ld_ok(int dt, int ny, int ld) { return ld >= ny && ((size_t)ld * esize(dt)) % 16 == 0; }
+
+int mg_dev_jacobi(int dtype, int nx, int ny, int ld, double hx, double hy, double omega, const void* u, const void* rhs,
+                  void* out, void* stream) {
+  CHECK_DEV(valid_dtype(dtype) && nx >= 3 && ny >= 3 && ld_ok(dtype, ny, ld), "mg_dev_jacobi: bad shape / pitch");
+  CHECK_DEV(u && rhs && out && u != out && aligned16(u) && aligned16(rhs) && aligned16(out), "mg_dev_jacobi: bad pointer");
+  d_jacobi(dtype, u, rhs, out, nx, ny, ld, hx, hy, omega, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_rbgs_colour(int dtype, int nx, int ny, int ld, double hx, double hy, double omega, int colour, int colour_offset,
+                       void* u, const void* rhs, void* stream) {
+  CHECK_DEV(valid_dtype(dtype) && nx >= 3 && ny >= 3 && ld_ok(dtype, ny, ld) && (colour == 0 || colour == 1), "mg_dev_rbgs_colour: bad argument");
+  CHECK_DEV(u && rhs && aligned16(u) && aligned16(rhs), "mg_dev_rbgs_colour: bad pointer");
+  d_rbgs_colour(dtype, u, rhs, nx, ny, ld, hx, hy, omega, colour, colour_offset, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_residual(int dtype, int nx, int ny, int ld, double hx, double hy, double coeff, const void* u, const void* f,
+                    void* r, void* stream) {
+  CHECK_DEV(valid_dtype(dtype) && nx >= 3 && ny >= 3 && ld_ok(dtype, ny, ld), "mg_dev_residual: bad shape / pitch");
+  CHECK_DEV(u && f && r && aligned16(u) && aligned16(f) && aligned16(r), "mg_dev_residual: bad pointer");
+  d_residual(dtype, u, f, r, nx, ny, ld, hx, hy, coeff, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes) {
+  CHECK_DEV(bytes && nx >= 1 && ny >= 1, "mg_dev_scratch_bytes: bad argument");
+  *bytes = (int64_t)sizeof(double) * 2048;
+  return MG_OK;
+}
+
+int mg_dev_sumsq(int dtype, int nx, int ny, int ld, const void* field, void* scratch, double* sumsq_dev, void* stream) {
+  CHECK_DEV(valid_dtype(dtype) && nx >= 1 && ny >= 1 && ld_ok(dtype, ny, ld), "mg_dev_sumsq: bad shape / pitch");
+  CHECK_DEV(field && scratch && sumsq_dev && aligned16(field), "mg_dev_sumsq: bad pointer");
+  const int n = d_sumsq(dtype, field, (double*)scratch, nx, ny, ld, (hipStream_t)stream);
+  launch_reduce((double*)scratch, n, sumsq_dev, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_restrict_fw(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int ldc, const void* fine, void* coarse,
+                       void* stream) {
+  CHECK_DEV(valid_dtype(in_dtype) && valid_dtype(out_dtype) && nxf >= 3 && nyf >= 3, "mg_dev_restrict_fw: bad argument");
+  CHECK_DEV((nxf - 1) % 2 == 0 && (nyf - 1) % 2 == 0, "Cannot coarsen grid: need even number of interior points");
+  CHECK_DEV(ld_ok(in_dtype, nyf, ldf) && ld_ok(out_dtype, (nyf - 1) / 2 + 1, ldc) && fine && coarse && aligned16(coarse), "mg_dev_restrict_fw: bad pitch / pointer");
+  d_restrict(in_dtype, out_dtype, fine, coarse, nxf, nyf, ldf, ldc, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int nxf, int nyf, int ldf, int ldc,
+                       const void* coarse, void* fine_u, void* stream) {
+  CHECK_DEV(valid_dtype(coarse_dtype) && valid_dtype(fine_dtype) && valid_dtype(compute_dtype) && nxf >= 3 && nyf >= 3, "mg_dev_prolong_add: bad argument");
+  CHECK_DEV((nxf - 1) % 2 == 0 && (nyf - 1) % 2 == 0, "fine grid is not a refinement (2*(n-1)+1)");
+  CHECK_DEV(ld_ok(fine_dtype, nyf, ldf) && ldc >= (nyf - 1) / 2 + 1 && coarse && fine_u && aligned16(fine_u), "mg_dev_prolong_add: bad pitch / pointer");
+  const int rc = d_prolong<true>(coarse_dtype, fine_dtype, compute_dtype, coarse, fine_u, nxf, nyf, ldf, ldc, (hipStream_t)stream);
+  if (rc != MG_OK) return fail(nullptr, rc, "mg_dev_prolong_add: fp32 interpolation needs fp32 coarse and fine fields");
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_convert(int in_dtype, int out_dtype, int nx, int ny, int ldi, int ldo, const void* in, void* out, void* stream) {
+  CHECK_DEV(valid_dtype(in_dtype) && valid_dtype(out_dtype) && nx >= 1 && ny >= 1 && ldi >= ny && ldo >= ny && in && out, "mg_dev_convert: bad argument");
+  d_convert(in_dtype, out_dtype, in, out, nx, ny, ldi, ldo, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+// ---------------------------------------------------------------- stateless, host arrays ------
+namespace {
+struct Scratch {   // device buffers of one host-pointer call, freed on scope exit
+  std::vector<void*> ptrs;
+  hipStream_t st = nullptr;
+  ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+  int get(void** p, int dt, int nx, int ny) {
+    const size_t bytes = (size_t)nx * pitch_elems(dt, ny) * esize(dt);
+    const int rc = alloc_zero(nullptr, p, bytes);
+    if (rc == MG_OK) ptrs.push_back(*p);
+    return rc;
+  }
+};
+int need_device() {
+  int n = 0;
+  const int rc = mg_device_count(&n);
+  if (rc != MG_OK) return rc;
+  if (n <= 0) return fail(nullptr, MG_ERR_NO_DEVICE, "no HIP device visible");
+  return MG_OK;
+}
+int up(void* dev, int dt, const void* host, int nx, int ny) {
+  const int ld = pitch_elems(dt, ny);
+  HIPC(nullptr, hipMemcpy2D(dev, (size_t)ld * esize(dt), host, (size_t)ny * esize(dt), (size_t)ny * esize(dt), nx, hipMemcpyHostToDevice));
+  return MG_OK;
+}
+int down(void* host, int dt, const void* dev, int nx, int ny) {
+  const int ld = pitch_elems(dt, ny);
+  HIPC(nullptr, hipDeviceSynchronize());
+  HIPC(nullptr, hipMemcpy2D(host, (size_t)ny * esize(dt), dev, (size_t)ld * esize(dt), (size_t)ny * esize(dt), nx, hipMemcpyDeviceToHost));
+  return MG_OK;
+}
+#define RC(x) do { const int rc_ = (x); if (rc_ != MG_OK) return rc_; } while (0)
+}  // namespace
+
+int mg_op_residual(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* u, const void* f, void* r) {
+  CHECK_DEV(valid_dtype(dtype) && u && f && r, "mg_op_residual: bad argument");
+  CHECK_DEV(nx >= 3 && ny >= 3, "Cannot apply Laplacian to grid");   // operators/laplacian.py:55-56
+  RC(need_device());
+  Scratch s; void *du, *df, *dr;
+  RC(s.get(&du, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny)); RC(s.get(&dr, dtype, nx, ny));
+  RC(up(du, dtype, u, nx, ny)); RC(up(df, dtype, f, nx, ny));
+  d_residual(dtype, du, df, dr, nx, ny, pitch_elems(dtype, ny), hx, hy, coeff, nullptr);
+  return down(r, dtype, dr, nx, ny);
+}
+
+int mg_op_apply(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* u, void* au) {
+  CHECK_DEV(valid_dtype(dtype) && u && au, "mg_op_apply: bad argument");
+  CHECK_DEV(nx >= 3 && ny >= 3, "Cannot apply Laplacian to grid");
+  RC(need_device());
+  // A u = 0 - (0 - A u): residual of a zero right-hand side under the negated coefficient (exact sign flips)
+  Scratch s; void *du, *df, *dr;
+  RC(s.get(&du, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny)); RC(s.get(&dr, dtype, nx, ny));
+  RC(up(du, dtype, u, nx, ny));
+  d_residual(dtype, du, df, dr, nx, ny, pitch_elems(dtype, ny), hx, hy, -coeff, nullptr);
+  return down(au, dtype, dr, nx, ny);
+}
+
+int mg_op_norm(int dtype, int nx, int ny, double hx, double hy, const void* field, double* out) {
+  CHECK_DEV(valid_dtype(dtype) && field && out && nx >= 1 && ny >= 1, "mg_op_norm: bad argument");
+  RC(need_device());
+  Scratch s; void* dfld; void* part; void* acc;
+  RC(s.get(&dfld, dtype, nx, ny));
+  RC(alloc_zero(nullptr, &part, sizeof(double) * 2048)); s.ptrs.push_back(part);
+  RC(alloc_zero(nullptr, &acc, sizeof(double))); s.ptrs.push_back(acc);
+  RC(up(dfld, dtype, field, nx, ny));
+  const int n = d_sumsq(dtype, dfld, (double*)part, nx, ny, pitch_elems(dtype, ny), nullptr);
+  launch_reduce((double*)part, n, (double*)acc, nullptr);
+  double ss = 0;
+  HIPC(nullptr, hipMemcpy(&ss, acc, sizeof(double), hipMemcpyDeviceToHost));
+  *out = std::sqrt(hx * hy * ss);
+  return MG_OK;
+}
+
+int mg_op_jacobi(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* u, const void* rhs, void* out) {
+  CHECK_DEV(valid_dtype(dtype) && u && rhs && out && nu >= 0 && nx >= 3 && ny >= 3, "mg_op_jacobi: bad argument");
+  RC(need_device());
+  Scratch s; void *da, *db, *df;
+  RC(s.get(&da, dtype, nx, ny)); RC(s.get(&db, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny));
+  RC(up(da, dtype, u, nx, ny)); RC(up(db, dtype, u, nx, ny)); RC(up(df, dtype, rhs, nx, ny));
+  for (int k = 0; k < nu; ++k) { d_jacobi(dtype, da, df, db, nx, ny, pitch_elems(dtype, ny), hx, hy, omega, nullptr); std::swap(da, db); }
+  return down(out, dtype, da, nx, ny);
+}
+
+int mg_op_rbgs(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* u, const void* rhs, void* out) {
+  CHECK_DEV(valid_dtype(dtype) && u && rhs && out && nu >= 0 && nx >= 3 && ny >= 3, "mg_op_rbgs: bad argument");
+  RC(need_device());
+  Scratch s; void *da, *df;
+  RC(s.get(&da, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny));
+  RC(up(da, dtype, u, nx, ny)); RC(up(df, dtype, rhs, nx, ny));
+  for (int k = 0; k < nu; ++k)
+    for (int c = 0; c < 2; ++c) d_rbgs_colour(dtype, da, df, nx, ny, pitch_elems(dtype, ny), hx, hy, omega, c, 0, nullptr);
+  return down(out, dtype, da, nx, ny);
+}
+
+int mg_op_restrict_fw(int in_dtype, int out_dtype, int nx, int ny, const void* fine, void* coarse) {
+  CHECK_DEV(valid_dtype(in_dtype) && valid_dtype(out_dtype) && fine && coarse, "mg_op_restrict_fw: bad argument");
+  CHECK_DEV(nx >= 3 && ny >= 3 && (nx - 1) % 2 == 0 && (ny - 1) % 2 == 0, "Cannot restrict: fine grid is not coarsenable");   // transfer.py:65-66
+  RC(need_device());
+  const int cx = (nx - 1) / 2 + 1, cy = (ny - 1) / 2 + 1;
+  Scratch s; void *dfine, *dc;
+  RC(s.get(&dfine, in_dtype, nx, ny)); RC(s.get(&dc, out_dtype, cx, cy));
+  RC(up(dfine, in_dtype, fine, nx, ny));
+  d_restrict(in_dtype, out_dtype, dfine, dc, nx, ny, pitch_elems(in_dtype, ny), pitch_elems(out_dtype, cy), nullptr);
+  return down(coarse, out_dtype, dc, cx, cy);
+}
+
+int mg_op_prolong_bilinear(int in_dtype, int out_dtype, int ncx, int ncy, const void* coarse, void* fine) {
+  CHECK_DEV(valid_dtype(in_dtype) && valid_dtype(out_dtype) && coarse && fine && ncx >= 2 && ncy >= 2, "mg_op_prolong_bilinear: bad argument");
+  RC(need_device());
+  const int nx = 2 * (ncx - 1) + 1, ny = 2 * (ncy - 1) + 1;
+  Scratch s; void *dc, *dfine;
+  RC(s.get(&dc, in_dtype, ncx, ncy)); RC(s.get(&dfine, out_dtype, nx, ny));
+  RC(up(dc, in_dtype, coarse, ncx, ncy));
+  // the interpolation runs in the FINE array's dtype (operators/transfer.py:207,236)
+  const int rc = d_prolong<false>(in_dtype, out_dtype, (in_dtype == MG_F32 && out_dtype == MG_F32) ? MG_F32 : MG_F64, dc, dfine,
+                                  nx, ny, pitch_elems(out_dtype, ny), pitch_elems(in_dtype, ncy), nullptr);
+  if (rc != MG_OK) return fail(nullptr, rc, "mg_op_prolong_bilinear: unsupported dtype combination");
+  return down(fine, out_dtype, dfine, nx, ny);
+}
+
+int mg_op_coarse_solve(int dtype, int nx, int ny, double hx, double hy, double coeff, double tol, int maxit, const void* u0,
+                       const void* rhs, void* out, int* sweeps) {
+  CHECK_DEV(valid_dtype(dtype) && u0 && rhs && out && nx >= 3 && ny >= 3 && maxit >= 1, "mg_op_coarse_solve: bad argument");
+  RC(need_device());
+  Scratch s; void *du, *df; void* dsw;
+  RC(s.get(&du, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny));
+  RC(alloc_zero(nullptr, &dsw, sizeof(int))); s.ptrs.push_back(dsw);
+  RC(up(du, dtype, u0, nx, ny)); RC(up(df, dtype, rhs, nx, ny));
+  d_coarse(dtype, du, df, nx, ny, pitch_elems(dtype, ny), hx, hy, coeff, 1.0, tol, maxit, (int*)dsw, nullptr);
+  RC(down(out, dtype, du, nx, ny));
+  if (sweeps) HIPC(nullptr, hipMemcpy(sweeps, dsw, sizeof(int), hipMemcpyDeviceToHost));
+  return MG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+"""Thin object wrapper of one mg_handle (include/mghip.h): the device-resident hierarchy."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class MultigridEngine:
+    """Owns a device-resident multigrid hierarchy.  All arguments are the fields of mg_config."""
+
+    def __init__(self, nx, ny, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0, max_levels=4, cycle="V", pre=2, post=2,
+                 smoother=_lib.MG_JACOBI, omega=0.8, coarse_tol=1e-12, coarse_maxit=1000,
+                 precision=_lib.MG_PREC_DOUBLE, switch_threshold=1e-6, memory_threshold_gb=4.0,
+                 adaptive_reference_rule=False, device=0, profile=False, colour_offset=0):
+        lib = _lib.load()
+        if isinstance(cycle, str):
+            if cycle not in _lib.CYCLES:
+                raise ValueError(f"unknown cycle type {cycle!r}")
+            cycle = _lib.CYCLES[cycle]
+        cfg = _lib.MgConfig(int(nx), int(ny), float(domain[0]), float(domain[1]), float(domain[2]), float(domain[3]),
+                            float(coeff), int(max_levels), int(cycle), int(pre), int(post), int(smoother),
+                            float(omega), float(coarse_tol), int(coarse_maxit), int(precision),
+                            float(switch_threshold), float(memory_threshold_gb), int(bool(adaptive_reference_rule)),
+                            int(device), int(bool(profile)), int(colour_offset))
+        self.cfg = cfg
+        self._h = C.c_void_p(None)
+        _lib.check(lib.mg_create(C.byref(cfg), C.byref(self._h)))
+        self._lib = lib
+        n = C.c_int(0)
+        self._check(lib.mg_num_levels(self._h, C.byref(n)))
+        self.num_levels = n.value
+        self.shapes = []
+        for l in range(self.num_levels):
+            a, b = C.c_int(0), C.c_int(0)
+            self._check(lib.mg_level_shape(self._h, l, C.byref(a), C.byref(b)))
+            self.shapes.append((a.value, b.value))
+        self.nx, self.ny = int(nx), int(ny)
+
+    def _check(self, rc):
+        _lib.check(rc, self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mg_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- whole solve ---------------------------------------------------------------------
+    def solve(self, rhs, u0=None, tol=1e-8, max_iterations=50, out_dtype=None):
+        rhs = _lib.as_c(rhs)
+        if rhs.shape != (self.nx, self.ny):
+            raise ValueError("Multigrid not properly setup or grid mismatch")
+        dt = rhs.dtype if out_dtype is None else np.dtype(out_dtype)
+        rhs = np.ascontiguousarray(rhs, dtype=dt)
+        u0c = None if u0 is None else np.ascontiguousarray(u0, dtype=dt)
+        if u0c is not None and u0c.shape != rhs.shape:
+            raise ValueError("initial guess shape does not match the grid")
+        out = np.empty_like(rhs)
+        hist = (C.c_double * max_iterations)()
+        prec = (C.c_int32 * max_iterations)()
+        nit, conv = C.c_int(0), C.c_int(0)
+        stats = _lib.MgStats()
+        self._check(self._lib.mg_solve(self._h, _lib.ptr(rhs), None if u0c is None else _lib.ptr(u0c), _lib.ptr(out),
+                                       _lib.dtype_code(dt), float(tol), int(max_iterations), hist, max_iterations,
+                                       C.byref(nit), C.byref(conv), prec, C.byref(stats)))
+        n = nit.value
+        return out, {
+            "iterations": n, "converged": bool(conv.value),
+            "residual_history": [hist[i] for i in range(n)],
+            "precision_codes": [prec[i] for i in range(n)],
+            "initial_residual": stats.initial_residual,
+            "solve_seconds": stats.solve_seconds, "h2d_seconds": stats.h2d_seconds,
+            "d2h_seconds": stats.d2h_seconds, "precision_switches": stats.precision_switches,
+            "last_coarse_sweeps": stats.last_coarse_sweeps,
+        }
+
+    def iterate(self, tol=0.0, max_iterations=20):
+        """The policy + cycle + norm loop on the fields already resident on the device (no transfers)."""
+        hist = (C.c_double * max_iterations)()
+        prec = (C.c_int32 * max_iterations)()
+        nit, conv = C.c_int(0), C.c_int(0)
+        stats = _lib.MgStats()
+        self._check(self._lib.mg_iterate(self._h, float(tol), int(max_iterations), hist, max_iterations,
+                                         C.byref(nit), C.byref(conv), prec, C.byref(stats)))
+        n = nit.value
+        return {"iterations": n, "converged": bool(conv.value), "residual_history": [hist[i] for i in range(n)],
+                "precision_codes": [prec[i] for i in range(n)], "initial_residual": stats.initial_residual,
+                "solve_seconds": stats.solve_seconds, "precision_switches": stats.precision_switches}
+
+    # ---- device-resident stepping ---------------------------------------------------------
+    def set_rhs(self, rhs):
+        rhs = _lib.as_c(rhs)
+        if rhs.shape != (self.nx, self.ny):
+            raise ValueError("Multigrid not properly setup or grid mismatch")
+        self._check(self._lib.mg_set_rhs(self._h, _lib.ptr(rhs), _lib.dtype_code(rhs.dtype)))
+
+    def set_solution(self, u0=None, dtype=np.float64):
+        if u0 is None:
+            self._check(self._lib.mg_set_solution(self._h, None, _lib.dtype_code(dtype)))
+        else:
+            u0 = _lib.as_c(u0)
+            self._check(self._lib.mg_set_solution(self._h, _lib.ptr(u0), _lib.dtype_code(u0.dtype)))
+
+    def get_solution(self, dtype=np.float64):
+        out = np.empty((self.nx, self.ny), dtype=dtype)
+        self._check(self._lib.mg_get_solution(self._h, _lib.ptr(out), _lib.dtype_code(dtype)))
+        return out
+
+    def cycle(self, n=1):
+        self._check(self._lib.mg_cycle(self._h, int(n)))
+
+    def residual_norm(self):
+        out = C.c_double(0.0)
+        self._check(self._lib.mg_residual_norm(self._h, C.byref(out)))
+        return out.value
+
+    def set_working_precision(self, dtype):
+        self._check(self._lib.mg_set_working_precision(self._h, _lib.dtype_code(dtype)))
+
+    def synchronize(self):
+        self._check(self._lib.mg_synchronize(self._h))
+
+    def time_op(self, op, level=0, dtype=np.float64, reps=20):
+        ops = {"jacobi": 0, "rbgs": 1, "residual": 2, "residual_norm": 3, "restrict": 4, "prolong": 5, "cycle": 6}
+        out = C.c_double(0.0)
+        self._check(self._lib.mg_time_op(self._h, ops[op] if isinstance(op, str) else int(op), int(level),
+                                         _lib.dtype_code(dtype), int(reps), C.byref(out)))
+        return out.value
+
+    def level_timings(self):
+        res = {}
+        for l in range(self.num_levels):
+            t = (C.c_double * 3)()
+            self._check(self._lib.mg_level_timings(self._h, l, t))
+            res[l] = {"smooth_time": t[0], "restrict_time": t[1], "prolong_time": t[2]}
+        return res

@@ -1,0 +1,158 @@
+"""GPU parity of the whole V/W/F-cycle driver against the reference's golden residual histories and
+final solutions (tests/golden/solves.npz, produced by the reference), through
+MultigridSolver.setup/solve -> mg_create/mg_solve.
+
+north_star tolerances: 1e-12 relative l-inf (fp64), 1e-5 (mixed)."""
+import re
+
+import numpy as np
+import pytest
+
+import mixed_precision_multigrid_solvers_for_pdes_amd as mg
+from oracle import mg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SOLVE_RE = re.compile(r"n(\d+)(?:x(\d+))?_(?:(nondyadic|random)_)?L(\d+)_([VWF])(\d\d)?_([a-z0-9]+)_(float64|float32|mixed|adaptive_ref)__hist")
+
+
+def _smoother(name):
+    return {"jacobi08": lambda: mg.WeightedJacobiSmoother(),
+            "vjacobi08": lambda: mg.EnhancedJacobiSolver(relaxation_parameter=0.8),
+            "jacobi23": lambda: mg.JacobiSmoother(),
+            "rbgs": lambda: mg.GaussSeidelSmoother(red_black=True),
+            "rbgs15": lambda: mg.GaussSeidelSmoother(red_black=True, relaxation_parameter=1.15),
+            "lexgs": lambda: mg.GaussSeidelSmoother()}[name]()
+
+
+def _run(g, key):
+    m = SOLVE_RE.fullmatch(key)
+    nx = int(m.group(1)); ny = int(m.group(2) or nx)
+    special, L, cyc, vv, sm, prec = m.group(3), int(m.group(4)), m.group(5), m.group(6), m.group(7), m.group(8)
+    pre, post = (int(vv[0]), int(vv[1])) if vv else (2, 2)
+    dom = (0.0, 1.5, -0.2, 0.5) if special == "nondyadic" else (0.0, 1.0, 0.0, 1.0)
+    dtype = np.float32 if prec == "float32" else np.float64
+    grid = mg.Grid(nx, ny, dom, dtype)
+    if special == "random":
+        rhs, u0, maxit = g["n33_random_rhs"], g["n33_random_u0"], 8
+    else:
+        rhs, u0 = O.sine_rhs(nx, ny, dom, dtype).astype(dtype), None
+        maxit = 12 if prec in ("float32", "adaptive_ref") else 30
+    pm = None
+    if prec == "mixed":
+        pm = mg.PrecisionManager(default_precision="mixed")
+    elif prec == "adaptive_ref":
+        pm = mg.PrecisionManager()
+    op = mg.LaplacianOperator(coefficient=-1.0)
+    s = mg.MultigridSolver(max_levels=L, max_iterations=maxit, tolerance=1e-10, cycle_type=cyc,
+                           pre_smooth_iterations=pre, post_smooth_iterations=post)
+    s.setup(grid, op, mg.RestrictionOperator("full_weighting"), mg.ProlongationOperator("bilinear"), smoother=_smoother(sm))
+    u, info = s.solve(grid, op, rhs, u0, pm)
+    s.cleanup()
+    return u, info, pm
+
+
+def _keys(g):
+    return sorted(k for k in g.files if k.endswith("__hist"))
+
+
+@pytest.mark.parametrize("idx", range(28))
+def test_golden_histories_and_solutions(golden_solves, idx):
+    g = golden_solves
+    keys = _keys(g)
+    if idx >= len(keys):
+        pytest.skip("fewer golden solves than slots")
+    key = keys[idx]
+    ref_hist = g[key]
+    u, info, pm = _run(g, key)
+    hist = np.array(info["residual_history"])
+    ukey = key.replace("__hist", "__u")
+    if key.endswith("_float64__hist"):
+        assert len(hist) == len(ref_hist), (key, hist, ref_hist)
+        # the norm is an fp64 reduction in a different order: 1e-10 relative, floor at fp64 round-off of the norm
+        np.testing.assert_allclose(hist, ref_hist, rtol=1e-9, atol=5e-14, err_msg=key)
+        assert info["iterations"] == len(ref_hist) and info["converged"] == bool(ref_hist[-1] < 1e-10)
+        if ukey in g.files:
+            ref_u = g[ukey]
+            rel = np.max(np.abs(u - ref_u)) / np.max(np.abs(ref_u))
+            assert rel <= 1e-12, (key, rel)
+    elif key.endswith("_mixed__hist"):
+        assert len(hist) == len(ref_hist)
+        np.testing.assert_allclose(hist, ref_hist, rtol=1e-3, atol=1e-12, err_msg=key)
+        ref_u = g[ukey]
+        assert np.max(np.abs(u - ref_u)) / np.max(np.abs(ref_u)) <= 1e-5
+    elif key.endswith("_float32__hist"):
+        # fp32 stalls at its round-off floor (~1.9e-3 at 129^2): same decay, same floor
+        k = 3
+        np.testing.assert_allclose(hist[:k], ref_hist[:k], rtol=2e-2, err_msg=key)
+        assert 0.3 < hist[-1] / ref_hist[-1] < 3.0
+        ref_u = g[ukey]
+        assert u.dtype == np.float32
+        assert np.max(np.abs(u - ref_u)) / np.max(np.abs(ref_u)) <= 1e-5
+    else:   # adaptive_ref: the reference's own rule drops to fp32 at iteration 1 and never returns (F11)
+        assert [p.value for p in pm.precision_history] == list(g[key.replace("__hist", "__precisions")])
+        np.testing.assert_allclose(hist[:3], ref_hist[:3], rtol=2e-2)
+        assert not info["converged"] and 0.3 < hist[-1] / ref_hist[-1] < 3.0
+        ref_u = g[ukey]
+        assert np.max(np.abs(u.astype(np.float64) - ref_u.astype(np.float64))) / np.max(np.abs(ref_u)) <= 1e-5
+
+
+def test_info_dict_contract(golden_solves):
+    """Keys of solvers/base.py:159-171 + solvers/multigrid.py:382-389."""
+    u, info, _ = _run(golden_solves, "n33_L4_V_jacobi08_float64__hist")
+    for k in ["converged", "iterations", "final_residual", "convergence_rate", "residual_history", "total_time",
+              "average_time_per_iteration", "precision_levels_used", "cycle_type", "num_levels", "grid_hierarchy",
+              "level_timings", "pre_smooth_iterations", "post_smooth_iterations"]:
+        assert k in info, k
+    assert info["grid_hierarchy"] == [(33, 33), (17, 17), (9, 9), (5, 5)] and info["num_levels"] == 4
+    assert info["precision_levels_used"] == ["double"]
+
+
+def test_config2_1025_fp64_history(golden_large):
+    """BASELINE config 2: 1025^2 fp64 V(2,2) Jacobi 0.8, 9 levels: the reference's 16-cycle history
+    (stalls at 2.0e-10), a strided sample of its solution, and its norms."""
+    n = 1025
+    grid = mg.Grid(n, n)
+    op = mg.LaplacianOperator(coefficient=-1.0)
+    s = mg.MultigridSolver(max_levels=9, max_iterations=16, tolerance=1e-10)
+    s.setup(grid, op, mg.RestrictionOperator(), mg.ProlongationOperator(), smoother=mg.EnhancedJacobiSolver(relaxation_parameter=0.8))
+    u, info = s.solve(grid, op, O.sine_rhs(n, n))
+    s.cleanup()
+    ref = golden_large["hist"]
+    hist = np.array(info["residual_history"])
+    assert len(hist) == len(ref) == 16
+    np.testing.assert_allclose(hist[:11], ref[:11], rtol=1e-7)        # above the round-off floor of the norm
+    assert np.all(np.abs(hist[11:] - ref[11:]) < 5e-11)                # at the floor (2e-10): same plateau
+    rel = np.max(np.abs(u[::32, ::32] - golden_large["u_sample"])) / float(golden_large["u_linf"])
+    assert rel <= 1e-12, rel
+    np.testing.assert_allclose(np.max(np.abs(u)), float(golden_large["u_linf"]), rtol=1e-12)
+    np.testing.assert_allclose(np.sqrt(np.sum(u * u)), float(golden_large["u_l2"]), rtol=1e-12)
+
+
+def test_config3_4097_adaptive_vs_fp64():
+    """BASELINE config 3: 4097^2 adaptive fp32->fp64 (switch_threshold 1e-6) against the fp64 run of
+    the same engine: <= 1e-5 relative l-inf (north_star), and the switch must have happened."""
+    n = 4097
+    f = lambda x, y: 2 * np.pi**2 * np.sin(np.pi * x) * np.sin(np.pi * y)
+    prob = mg.PoissonProblem(f, nx=n, ny=n, analytical_solution=lambda x, y: np.sin(np.pi * x) * np.sin(np.pi * y))
+    u64, i64 = mg.MixedPrecisionMultigrid("double", tolerance=1e-7, max_iterations=25).solve(prob)
+    ua, ia = mg.MixedPrecisionMultigrid("adaptive", switch_threshold=1e-6, tolerance=1e-7, max_iterations=40).solve(prob)
+    assert i64["converged"] and ia["converged"]
+    assert set(ia["precision_levels_used"]) == {"float32", "float64"}
+    assert np.max(np.abs(ua - u64)) / np.max(np.abs(u64)) <= 1e-5
+    assert ia["max_error"] < 1e-6 and i64["max_error"] < 1e-6          # O(h^2) discretisation error
+
+
+def test_device_resident_stepping_equals_solve():
+    n = 257
+    rhs = O.sine_rhs(n, n)
+    eng = mg.MultigridEngine(n, n, max_levels=7, smoother=0, omega=0.8)
+    u, r = eng.solve(rhs, tol=1e-30, max_iterations=5)
+    eng.set_rhs(rhs); eng.set_solution(None)
+    hist = []
+    for _ in range(5):
+        eng.cycle(1)
+        hist.append(eng.residual_norm())
+    np.testing.assert_array_equal(eng.get_solution(), u)
+    np.testing.assert_array_equal(hist, r["residual_history"])
+    eng.close()
