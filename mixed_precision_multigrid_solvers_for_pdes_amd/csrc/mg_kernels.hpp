@@ -100,11 +100,13 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ u, T* __restric
 //   reference: solvers/smoothers.py:62-84 (loop form), solvers/iterative.py:84-104 (vectorised):
 //     nb = ihx2*(u[i+1,j]+u[i-1,j]) + ihy2*(u[i,j+1]+u[i,j-1]);  un = (rhs+nb)/D;
 //     out = (1-w)*u + w*un on interior cells; boundary cells copied through.
+//   DIV = false when 1/D is exact (D a power of two: square cells with dyadic h), else a true IEEE
+//   division keeps the reference's rounding.
 //   algorithmic traffic: read u, read rhs, write out = 3 words / DoF.
 // --------------------------------------------------------------------------------------------
-template <typename T, int TAG>
+template <typename T, int TAG, bool DIV>
 __global__ __launch_bounds__(kBlock) void jacobi_kernel(const T* __restrict__ u, const T* __restrict__ rhs,
-                                                        T* __restrict__ out, TileGeom g, T ihx2, T ihy2, T invD,
+                                                        T* __restrict__ out, TileGeom g, T ihx2, T ihy2, T invD, T D,
                                                         T omega, T one_m_omega) {
   using S = TileShape<T>;
   __shared__ __attribute__((aligned(16))) T s[S::LDS_ELEMS];
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void jacobi_kernel(const T* __restrict__ u,
       const T w = (e == 0) ? left : mid.v[e - 1];
       const T ea = (e == S::N - 1) ? right : mid.v[e + 1];
       const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
-      const T un = (f[k].v[e] + nb) * invD;
+      const T un = DIV ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
       const T res = one_m_omega * mid.v[e] + omega * un;
       const int gj = gj0 + e;
       o.v[e] = (row_in && gj >= 1 && gj < g.ny - 1) ? res : mid.v[e];
@@ -158,9 +160,9 @@ __global__ __launch_bounds__(kBlock) void jacobi_kernel(const T* __restrict__ u,
 //   Same-colour cells never neighbour each other, so in-place update within a launch is race free:
 //   a launch reads only the other colour (plus its own centre value) and writes only its colour.
 // --------------------------------------------------------------------------------------------
-template <typename T, int TAG>
+template <typename T, int TAG, bool DIV>
 __global__ __launch_bounds__(kBlock) void rbgs_colour_kernel(T* __restrict__ u, const T* __restrict__ rhs, TileGeom g,
-                                                             T ihx2, T ihy2, T invD, T omega, T one_m_omega,
+                                                             T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega,
                                                              int colour, int poff) {
   using S = TileShape<T>;
   __shared__ __attribute__((aligned(16))) T s[S::LDS_ELEMS];
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void rbgs_colour_kernel(T* __restrict__ u, 
       const T w = (e == 0) ? left : mid.v[e - 1];
       const T ea = (e == S::N - 1) ? right : mid.v[e + 1];
       const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
-      const T un = (f[k].v[e] + nb) * invD;
+      const T un = DIV ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
       const T res = one_m_omega * mid.v[e] + omega * un;
       const int gj = gj0 + e;
       const bool mine = (((gi + gj + poff) & 1) == colour);
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void convert_kernel(const TIN* __restrict__
 // --------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u, const T* __restrict__ rhs, int nx,
-                                                              int ny, int ld, T ihx2, T ihy2, T invD, T omega,
+                                                              int ny, int ld, T hx2, T hy2, T omega,
                                                               T one_m_omega, T diag, T coeff, double hxhy, double tol,
                                                               int maxit, int* __restrict__ sweeps_out) {
   __shared__ double red[kBlock / 64];
@@ -436,8 +438,8 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
       for (int i = ilo + (int)threadIdx.x; i <= ihi; i += kBlock) {
         const int j = sdiag - i;
         T* p = u + (size_t)i * ld + j;
-        const T nb = ihx2 * (p[ld] + p[-ld]) + ihy2 * (p[1] + p[-1]);
-        const T un = (rhs[(size_t)i * ld + j] + nb) * invD;
+        const T nb = (p[ld] + p[-ld]) / hx2 + (p[1] + p[-1]) / hy2;
+        const T un = (rhs[(size_t)i * ld + j] + nb) / diag;
         p[0] = one_m_omega * p[0] + omega * un;
       }
       __syncthreads();
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
       const T* p = u + (size_t)i * ld + j;
       T rv = rhs[(size_t)i * ld + j];
       if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1)
-        rv = rv - coeff * (((p[ld] + p[-ld]) * ihx2 + (p[1] + p[-1]) * ihy2) - p[0] * diag);
+        rv = rv - coeff * (((p[ld] + p[-ld]) / hx2 + (p[1] + p[-1]) / hy2) - p[0] * diag);
       acc += (double)rv * (double)rv;
     }
     const double t = block_reduce_sum(acc, red);

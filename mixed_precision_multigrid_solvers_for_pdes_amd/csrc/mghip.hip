@@ -66,6 +66,7 @@ mg::TileGeom make_geom(int nx, int ny, int ld, bool interior_only) {
 
 struct Coef {
   double ihx2, ihy2, diag, invD;
+  bool pow2;   // 1/diag is exact: multiply instead of divide
 };
 inline Coef coefs(double hx, double hy) {
   Coef c;
@@ -73,6 +74,8 @@ inline Coef coefs(double hx, double hy) {
   c.ihy2 = 1.0 / (hy * hy);
   c.diag = 2.0 / (hx * hx) + 2.0 / (hy * hy);   // operators/laplacian.py:76, smoothers.py:65
   c.invD = 1.0 / c.diag;
+  int e = 0;
+  c.pow2 = std::frexp(c.diag, &e) == 0.5;
   return c;
 }
 
@@ -88,9 +91,10 @@ void launch_jacobi(const void* u, const void* rhs, void* out, int nx, int ny, in
   if (nx < 3 || ny < 3) return;
   const Coef c = coefs(hx, hy);
   const mg::TileGeom g = make_geom<T>(nx, ny, ld, true);
-  auto k = fine ? mg::jacobi_kernel<T, mg::kFineTag> : mg::jacobi_kernel<T, mg::kCoarseTag>;
+  auto k = c.pow2 ? (fine ? mg::jacobi_kernel<T, mg::kFineTag, false> : mg::jacobi_kernel<T, mg::kCoarseTag, false>)
+                  : (fine ? mg::jacobi_kernel<T, mg::kFineTag, true> : mg::jacobi_kernel<T, mg::kCoarseTag, true>);
   hipLaunchKernelGGL(k, dim3(g.ntiles), dim3(mg::kBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out,
-                     g, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)omega, (T)(1.0 - omega));
+                     g, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega));
 }
 
 template <typename T>
@@ -99,9 +103,10 @@ void launch_rbgs_colour(void* u, const void* rhs, int nx, int ny, int ld, double
   if (nx < 3 || ny < 3) return;
   const Coef c = coefs(hx, hy);
   const mg::TileGeom g = make_geom<T>(nx, ny, ld, true);
-  auto k = fine ? mg::rbgs_colour_kernel<T, mg::kFineTag> : mg::rbgs_colour_kernel<T, mg::kCoarseTag>;
+  auto k = c.pow2 ? (fine ? mg::rbgs_colour_kernel<T, mg::kFineTag, false> : mg::rbgs_colour_kernel<T, mg::kCoarseTag, false>)
+                  : (fine ? mg::rbgs_colour_kernel<T, mg::kFineTag, true> : mg::rbgs_colour_kernel<T, mg::kCoarseTag, true>);
   hipLaunchKernelGGL(k, dim3(g.ntiles), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, g,
-                     (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)omega, (T)(1.0 - omega), colour, poff & 1);
+                     (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), colour, poff & 1);
 }
 
 // returns the number of partials written (0 when NORM is off)
@@ -154,7 +159,7 @@ void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, 
                    double tol, int maxit, int* sweeps_dev, hipStream_t st) {
   const Coef c = coefs(hx, hy);
   hipLaunchKernelGGL(mg::coarse_lexgs_kernel<T>, dim3(1), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
-                     (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol,
+                     (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol,
                      maxit, sweeps_dev);
 }
 

@@ -16,11 +16,9 @@ def pytest_configure(config):
 
 
 def _have_gpu():
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
+    """A machine with the AMD compute device node is a GPU box: there the gpu-marked tests RUN (and fail
+    loudly if the runtime is broken) instead of being skipped on a flaky availability probe."""
+    return os.path.exists("/dev/kfd")
 
 
 def pytest_collection_modifyitems(config, items):
