@@ -87,6 +87,27 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheel bundles its own libamdhip64.so / libhsa-runtime64.so and loads them by path.
+    Two HIP runtimes in one process cannot both own the device (the second reports "no ROCm-capable
+    device"), so whichever of {torch, libmghip} comes first must bring in the SAME copy: when torch is
+    installed but not imported yet, preload its libamdhip64.so so that libmghip.so binds to it by SONAME
+    and a later `import torch` finds its own file already mapped."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def library_path():
     return os.environ.get("MGHIP_LIBRARY", _build.LIBPATH)
 
@@ -106,6 +127,7 @@ def load():
     if not os.path.exists(path):
         raise ImportError(f"libmghip.so not found at {path}; run `python -m "
                           "mixed_precision_multigrid_solvers_for_pdes_amd._build`")
+    _share_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)                       # AttributeError if the ABI is incomplete
@@ -150,6 +172,11 @@ def device_count():
     n = C.c_int(0)
     rc = load().mg_device_count(C.byref(n))
     return n.value if rc == MG_OK else 0
+
+
+def on_gpu_box():
+    """True where the AMD compute device node exists."""
+    return os.path.exists("/dev/kfd")
 
 
 def as_c(a, dtype=None):
