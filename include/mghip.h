@@ -123,6 +123,13 @@ int mg_cycle(mg_handle* h, int ncycles);           /* asynchronous on the handle
 int mg_residual_norm(mg_handle* h, double* out);   /* sqrt(hx*hy*sum r^2), synchronises           */
 int mg_set_working_precision(mg_handle* h, int dtype); /* MG_PREC_ADAPTIVE only: in-device cast of u */
 int mg_synchronize(mg_handle* h);
+/* Queue the handle's work on the caller's stream (use_own = 0) or back on its own (use_own = 1). */
+int mg_set_stream(mg_handle* h, void* stream, int use_own);
+/* Device-to-device forms of mg_set_rhs / mg_set_solution(NULL) / mg_get_solution: (nx, ny) arrays with pitch
+ * `ld`, converted to/from the handle's working precision on the handle's stream, asynchronous. */
+int mg_set_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype);
+int mg_zero_solution_device(mg_handle* h);
+int mg_get_solution_device(mg_handle* h, void* u_dev, int ld, int dtype);
 /* the stream all of the handle's work is queued on (a hipStream_t), for callers that bracket with events */
 int mg_get_stream(mg_handle* h, void** stream);
 
@@ -158,12 +165,18 @@ int mg_dev_rbgs_colour(int dtype, int nx, int ny, int ld, double hx, double hy, 
                        int colour_offset, void* u, const void* rhs, void* stream);
 int mg_dev_residual(int dtype, int nx, int ny, int ld, double hx, double hy, double coeff,
                     const void* u, const void* f, void* r, void* stream);
-/* sum of squares into *sumsq_dev (one double in device memory); scratch >= mg_dev_scratch_bytes() */
-int mg_dev_sumsq(int dtype, int nx, int ny, int ld, const void* field, void* scratch, double* sumsq_dev, void* stream);
-int mg_dev_restrict_fw(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int ldc,
+/* sum of squares of field[i_lo:i_hi, j_lo:j_hi] into *sumsq_dev (one double in device memory);
+ * scratch >= mg_dev_scratch_bytes().  The window lets a sub-domain count the cells it owns. */
+int mg_dev_sumsq(int dtype, int ld, int i_lo, int i_hi, int j_lo, int j_hi, const void* field, void* scratch,
+                 double* sumsq_dev, void* stream);
+/* Sub-domain forms of the transfers.  Coarse cell (ic, jc) sits on fine cell (2ic, 2jc).  `sides` is a bit
+ * mask of the edges of THIS array that are physical boundaries (1: i = 0, 2: i = n-1, 4: j = 0, 8: j = n-1;
+ * 15 for a whole grid); the remaining edges are ghost rings owned by a neighbouring sub-domain: restriction
+ * leaves those coarse cells untouched, prolongation interpolates them from the coarse ghost values. */
+int mg_dev_restrict_fw(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides,
                        const void* fine, void* coarse, void* stream);
-int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int nxf, int nyf, int ldf, int ldc,
-                       const void* coarse, void* fine_u, void* stream);
+int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int nxf, int nyf, int ldf, int nxc,
+                       int nyc, int ldc, int sides, const void* coarse, void* fine_u, void* stream);
 int mg_dev_convert(int in_dtype, int out_dtype, int nx, int ny, int ldi, int ldo, const void* in, void* out, void* stream);
 int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes);
 /* pitch (elements) the library itself uses for an (nx, ny) field of `dtype` */

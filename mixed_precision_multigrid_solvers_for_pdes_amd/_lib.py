@@ -76,9 +76,13 @@ SIGNATURES = {
     "mg_dev_jacobi": (_i, [_i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "mg_dev_rbgs_colour": (_i, [_i, _i, _i, _i, _d, _d, _d, _i, _i, _vp, _vp, _vp]),
     "mg_dev_residual": (_i, [_i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
-    "mg_dev_sumsq": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "mg_dev_restrict_fw": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "mg_dev_prolong_add": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mg_dev_sumsq": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mg_dev_restrict_fw": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mg_dev_prolong_add": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mg_set_stream": (_i, [_vp, _vp, _i]),
+    "mg_set_rhs_device": (_i, [_vp, _vp, _i, _i]),
+    "mg_zero_solution_device": (_i, [_vp]),
+    "mg_get_solution_device": (_i, [_vp, _vp, _i, _i]),
     "mg_dev_convert": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mg_dev_scratch_bytes": (_i, [_i, _i, C.POINTER(C.c_int64)]),
     "mg_pitch_elems": (_i, [_i, _i, _pi]),

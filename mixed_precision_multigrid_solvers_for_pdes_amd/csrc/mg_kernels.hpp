@@ -293,21 +293,25 @@ __global__ __launch_bounds__(kBlock) void residual_kernel(const T* __restrict__ 
   }
 }
 
-// Plain sum of squares of a field (reference: core/grid.py:187 without the hx*hy factor and sqrt).
+// Sum of squares of field[i_lo:i_hi, j_lo:j_hi] (reference: core/grid.py:187 without the hx*hy factor and
+// sqrt).  The window lets a sub-domain count exactly the cells it owns (plus its physical boundary).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void sumsq_kernel(const T* __restrict__ x, double* __restrict__ partials, int nx,
-                                                       int ny, int ld) {
+__global__ __launch_bounds__(kBlock) void sumsq_kernel(const T* __restrict__ x, double* __restrict__ partials, int ld,
+                                                       int i_lo, int i_hi, int j_lo, int j_hi) {
   constexpr int N = VecW<T>::N;
   __shared__ double red[kBlock / 64];
-  const int vpr = (ny + N - 1) / N;
-  const long long total = (long long)nx * vpr;
+  const int c_lo = j_lo / N, c_hi = (j_hi + N - 1) / N;
+  const int vpr = c_hi - c_lo;
+  const long long total = (long long)(i_hi - i_lo) * vpr;
   double acc = 0.0;
   for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
-    const int i = (int)(v / vpr), c = (int)(v - (long long)i * vpr);
+    const int i = i_lo + (int)(v / vpr), c = c_lo + (int)(v % vpr);
     const Pack<T> p = ldg(x + (size_t)i * ld + c * N);
 #pragma unroll
-    for (int e = 0; e < N; ++e)
-      if (c * N + e < ny) acc += (double)p.v[e] * (double)p.v[e];
+    for (int e = 0; e < N; ++e) {
+      const int j = c * N + e;
+      if (j >= j_lo && j < j_hi) acc += (double)p.v[e] * (double)p.v[e];
+    }
   }
   const double t = block_reduce_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
@@ -324,38 +328,43 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* _
 }
 
 // --------------------------------------------------------------------------------------------
-// Full-weighting restriction, fine (nx,ny) -> coarse ((nx-1)/2+1, (ny-1)/2+1).
+// Full-weighting restriction, fine (nxf,nyf) -> coarse (nxc,nyc); coarse (ic,jc) sits on fine (2ic,2jc).
 //   reference: operators/transfer.py:100-124 -- interior:
 //     1/16*(((NW+NE)+SW)+SE) + 1/8*(((N+S)+W)+E) + 1/4*C   evaluated in the FIELD's dtype,
 //     result stored in the coarse grid's dtype; coarse boundary = injection.
+//   `sides` says which edges of this array are PHYSICAL boundaries (bit 0: i = 0, 1: i = nxc-1,
+//   2: j = 0, 3: j = nyc-1).  A whole grid has all four; on a sub-domain the other edges are ghost
+//   rings owned by a neighbour: those coarse cells are left untouched (filled by the halo exchange).
 //   One thread produces one vector of coarse cells of one coarse row.
 // --------------------------------------------------------------------------------------------
+constexpr int kSideILo = 1, kSideIHi = 2, kSideJLo = 4, kSideJHi = 8, kAllSides = 15;
+
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(kBlock) void restrict_fw_kernel(const TIN* __restrict__ fine, TOUT* __restrict__ coarse,
-                                                             int nxf, int nyf, int ldf, int nxc, int nyc, int ldc) {
+                                                             int ldf, int nxc, int nyc, int ldc, int sides) {
   constexpr int NO = VecW<TOUT>::N;
-  const int vpr = ldc / NO;
+  const int vpr = (nyc + NO - 1) / NO;
   const long long total = (long long)nxc * vpr;
   for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
     const int ic = (int)(v / vpr), c = (int)(v - (long long)ic * vpr);
     const int jc0 = c * NO;
     const int fi = 2 * ic;
-    Pack<TOUT> o;
+    Pack<TOUT> o = ldg(coarse + (size_t)ic * ldc + jc0);
 #pragma unroll
     for (int e = 0; e < NO; ++e) {
       const int jc = jc0 + e, fj = 2 * jc;
-      TOUT val = TOUT(0);
-      if (jc < nyc) {
-        const TIN* p = fine + (size_t)fi * ldf + fj;
-        if (ic == 0 || ic == nxc - 1 || jc == 0 || jc == nyc - 1) {
-          val = (TOUT)p[0];
-        } else {
-          const TIN corners = ((p[-ldf - 1] + p[-ldf + 1]) + p[ldf - 1]) + p[ldf + 1];
-          const TIN edges = ((p[-ldf] + p[ldf]) + p[-1]) + p[1];
-          val = (TOUT)((TIN(1.0 / 16.0) * corners + TIN(1.0 / 8.0) * edges) + TIN(1.0 / 4.0) * p[0]);
-        }
+      if (jc >= nyc) continue;
+      const bool edge_i = (ic == 0) || (ic == nxc - 1), edge_j = (jc == 0) || (jc == nyc - 1);
+      const TIN* p = fine + (size_t)fi * ldf + fj;
+      if (!edge_i && !edge_j) {
+        const TIN corners = ((p[-ldf - 1] + p[-ldf + 1]) + p[ldf - 1]) + p[ldf + 1];
+        const TIN edges = ((p[-ldf] + p[ldf]) + p[-1]) + p[1];
+        o.v[e] = (TOUT)((TIN(1.0 / 16.0) * corners + TIN(1.0 / 8.0) * edges) + TIN(1.0 / 4.0) * p[0]);
+      } else {
+        const bool ghost = (ic == 0 && !(sides & kSideILo)) || (ic == nxc - 1 && !(sides & kSideIHi)) ||
+                           (jc == 0 && !(sides & kSideJLo)) || (jc == nyc - 1 && !(sides & kSideJHi));
+        if (!ghost) o.v[e] = (TOUT)p[0];     // physical boundary: injection
       }
-      o.v[e] = val;
     }
     stg(coarse + (size_t)ic * ldc + jc0, o);
   }
@@ -366,36 +375,41 @@ __global__ __launch_bounds__(kBlock) void restrict_fw_kernel(const TIN* __restri
 //   reference: operators/transfer.py:234-267 + solvers/multigrid.py:329.  Interpolation is evaluated
 //   in TC (the fine GRID's dtype in the reference), the sum u + Pe in the wider of (TF, TC), then
 //   rounded to TF -- NumPy's `u += fine_correction` semantics.
-//   Quirk F9 reproduced: (odd i, j == ny-1) and (i == nx-1, odd j) receive 0.
+//   Quirk F9 reproduced on PHYSICAL far edges (sides bits 1 and 3): (odd i, j == ny-1) and
+//   (i == nx-1, odd j) receive 0.  On a sub-domain the far edge may be a ghost ring instead, which is
+//   interpolated like any other cell from the (exchanged) coarse ghost values; fine cells whose coarse
+//   partners fall outside the coarse array (nxc, nyc) are left untouched.
 // --------------------------------------------------------------------------------------------
 template <typename TC_IN, typename TF, typename TC, bool ADD>
 __global__ __launch_bounds__(kBlock) void prolong_kernel(const TC_IN* __restrict__ e, TF* __restrict__ u, int nxf,
-                                                         int nyf, int ldf, int ldc) {
+                                                         int nyf, int ldf, int nxc, int nyc, int ldc, int sides) {
   constexpr int N = VecW<TF>::N;
   using TS = typename std::conditional<(sizeof(TC) > sizeof(TF)), TC, TF>::type;
-  const int vpr = ldf / N;
+  const int vpr = (nyf + N - 1) / N;
   const long long total = (long long)nxf * vpr;
   for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
     const int i = (int)(v / vpr), c = (int)(v - (long long)i * vpr);
     const int j0 = c * N;
     const int ic = i >> 1;
     const bool iodd = i & 1;
+    if (ic + (iodd ? 1 : 0) >= nxc) continue;
     const TC_IN* r0 = e + (size_t)ic * ldc;
     const TC_IN* r1 = r0 + (iodd ? ldc : 0);
-    Pack<TF> uo = ADD ? ldg(u + (size_t)i * ldf + j0) : zero_pack<TF>();
+    Pack<TF> uo = ldg(u + (size_t)i * ldf + j0);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const int j = j0 + k;
       if (j >= nyf) continue;
       const int jc = j >> 1;
       const bool jodd = j & 1;
+      if (jc + (jodd ? 1 : 0) >= nyc) continue;
       TC val;
       if (!iodd && !jodd) {
         val = (TC)r0[jc];
       } else if (iodd && !jodd) {
-        val = (j < nyf - 1) ? TC(0.5) * ((TC)r0[jc] + (TC)r1[jc]) : TC(0);
+        val = ((sides & kSideJHi) && j == nyf - 1) ? TC(0) : TC(0.5) * ((TC)r0[jc] + (TC)r1[jc]);
       } else if (!iodd && jodd) {
-        val = (i < nxf - 1) ? TC(0.5) * ((TC)r0[jc] + (TC)r0[jc + 1]) : TC(0);
+        val = ((sides & kSideIHi) && i == nxf - 1) ? TC(0) : TC(0.5) * ((TC)r0[jc] + (TC)r0[jc + 1]);
       } else {
         val = TC(0.25) * ((((TC)r0[jc] + (TC)r0[jc + 1]) + (TC)r1[jc]) + (TC)r1[jc + 1]);
       }

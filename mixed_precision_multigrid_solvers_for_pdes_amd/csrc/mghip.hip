@@ -122,10 +122,12 @@ int launch_residual(const void* u, const void* f, void* r, double* partials, int
 }
 
 template <typename T>
-int launch_sumsq(const void* x, double* partials, int nx, int ny, int ld, hipStream_t st) {
+int launch_sumsq(const void* x, double* partials, int ld, int i_lo, int i_hi, int j_lo, int j_hi, hipStream_t st) {
   const int N = mg::VecW<T>::N;
-  const int nb = std::min(grid_for((long long)nx * ((ny + N - 1) / N)), 2048);
-  hipLaunchKernelGGL(mg::sumsq_kernel<T>, dim3(nb), dim3(mg::kBlock), 0, st, (const T*)x, partials, nx, ny, ld);
+  const long long vecs = (long long)std::max(0, i_hi - i_lo) * ((j_hi + N - 1) / N - j_lo / N);
+  const int nb = std::min(grid_for(vecs), 2048);
+  hipLaunchKernelGGL(mg::sumsq_kernel<T>, dim3(nb), dim3(mg::kBlock), 0, st, (const T*)x, partials, ld, i_lo, i_hi, j_lo,
+                     j_hi);
   return nb;
 }
 
@@ -134,18 +136,18 @@ inline void launch_reduce(const double* partials, int n, double* out, hipStream_
 }
 
 template <typename TI, typename TO>
-void launch_restrict(const void* fine, void* coarse, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
-  const int nxc = (nxf - 1) / 2 + 1, nyc = (nyf - 1) / 2 + 1;
+void launch_restrict(const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, int sides, hipStream_t st) {
   const int NO = mg::VecW<TO>::N;
-  hipLaunchKernelGGL((mg::restrict_fw_kernel<TI, TO>), dim3(grid_for((long long)nxc * (ldc / NO))), dim3(mg::kBlock), 0,
-                     st, (const TI*)fine, (TO*)coarse, nxf, nyf, ldf, nxc, nyc, ldc);
+  hipLaunchKernelGGL((mg::restrict_fw_kernel<TI, TO>), dim3(grid_for((long long)nxc * ((nyc + NO - 1) / NO))),
+                     dim3(mg::kBlock), 0, st, (const TI*)fine, (TO*)coarse, ldf, nxc, nyc, ldc, sides);
 }
 
 template <typename TCI, typename TF, typename TC, bool ADD>
-void launch_prolong(const void* e, void* u, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
+void launch_prolong(const void* e, void* u, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides,
+                    hipStream_t st) {
   const int N = mg::VecW<TF>::N;
-  hipLaunchKernelGGL((mg::prolong_kernel<TCI, TF, TC, ADD>), dim3(grid_for((long long)nxf * (ldf / N))),
-                     dim3(mg::kBlock), 0, st, (const TCI*)e, (TF*)u, nxf, nyf, ldf, ldc);
+  hipLaunchKernelGGL((mg::prolong_kernel<TCI, TF, TC, ADD>), dim3(grid_for((long long)nxf * ((nyf + N - 1) / N))),
+                     dim3(mg::kBlock), 0, st, (const TCI*)e, (TF*)u, nxf, nyf, ldf, nxc, nyc, ldc, sides);
 }
 
 template <typename TI, typename TO>
@@ -184,27 +186,38 @@ int d_residual_norm(int dt, const void* u, const void* f, double* partials, int 
   if (dt == MG_F32) return launch_residual<float, false, true>(u, f, nullptr, partials, nx, ny, ld, hx, hy, coeff, st, fine);
   return launch_residual<double, false, true>(u, f, nullptr, partials, nx, ny, ld, hx, hy, coeff, st, fine);
 }
-int d_sumsq(int dt, const void* x, double* partials, int nx, int ny, int ld, hipStream_t st) {
-  return dt == MG_F32 ? launch_sumsq<float>(x, partials, nx, ny, ld, st) : launch_sumsq<double>(x, partials, nx, ny, ld, st);
+int d_sumsq(int dt, const void* x, double* partials, int ld, int i_lo, int i_hi, int j_lo, int j_hi, hipStream_t st) {
+  return dt == MG_F32 ? launch_sumsq<float>(x, partials, ld, i_lo, i_hi, j_lo, j_hi, st)
+                      : launch_sumsq<double>(x, partials, ld, i_lo, i_hi, j_lo, j_hi, st);
+}
+// whole-grid form: coarse dims follow from the fine ones and all four edges are physical boundaries
+void d_restrict_sub(int di, int dout, const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, int sides,
+                    hipStream_t st) {
+  if (di == MG_F32 && dout == MG_F32) launch_restrict<float, float>(fine, coarse, ldf, nxc, nyc, ldc, sides, st);
+  else if (di == MG_F64 && dout == MG_F64) launch_restrict<double, double>(fine, coarse, ldf, nxc, nyc, ldc, sides, st);
+  else if (di == MG_F64 && dout == MG_F32) launch_restrict<double, float>(fine, coarse, ldf, nxc, nyc, ldc, sides, st);
+  else launch_restrict<float, double>(fine, coarse, ldf, nxc, nyc, ldc, sides, st);
 }
 void d_restrict(int di, int dout, const void* fine, void* coarse, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
-  if (di == MG_F32 && dout == MG_F32) launch_restrict<float, float>(fine, coarse, nxf, nyf, ldf, ldc, st);
-  else if (di == MG_F64 && dout == MG_F64) launch_restrict<double, double>(fine, coarse, nxf, nyf, ldf, ldc, st);
-  else if (di == MG_F64 && dout == MG_F32) launch_restrict<double, float>(fine, coarse, nxf, nyf, ldf, ldc, st);
-  else launch_restrict<float, double>(fine, coarse, nxf, nyf, ldf, ldc, st);
+  d_restrict_sub(di, dout, fine, coarse, ldf, (nxf - 1) / 2 + 1, (nyf - 1) / 2 + 1, ldc, mg::kAllSides, st);
 }
 // dc: dtype of the coarse field, df: of the fine field, dcomp: interpolation arithmetic (the fine GRID's dtype)
 template <bool ADD>
-int d_prolong(int dc, int df, int dcomp, const void* e, void* u, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
+int d_prolong_sub(int dc, int df, int dcomp, const void* e, void* u, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc,
+                  int sides, hipStream_t st) {
   if (dcomp == MG_F32) {
-    if (dc == MG_F32 && df == MG_F32) { launch_prolong<float, float, float, ADD>(e, u, nxf, nyf, ldf, ldc, st); return MG_OK; }
+    if (dc == MG_F32 && df == MG_F32) { launch_prolong<float, float, float, ADD>(e, u, nxf, nyf, ldf, nxc, nyc, ldc, sides, st); return MG_OK; }
     return MG_ERR_INVALID_VALUE;   // fp32 interpolation only exists for an all-fp32 grid
   }
-  if (dc == MG_F64 && df == MG_F64) launch_prolong<double, double, double, ADD>(e, u, nxf, nyf, ldf, ldc, st);
-  else if (dc == MG_F32 && df == MG_F64) launch_prolong<float, double, double, ADD>(e, u, nxf, nyf, ldf, ldc, st);
-  else if (dc == MG_F64 && df == MG_F32) launch_prolong<double, float, double, ADD>(e, u, nxf, nyf, ldf, ldc, st);
-  else launch_prolong<float, float, double, ADD>(e, u, nxf, nyf, ldf, ldc, st);
+  if (dc == MG_F64 && df == MG_F64) launch_prolong<double, double, double, ADD>(e, u, nxf, nyf, ldf, nxc, nyc, ldc, sides, st);
+  else if (dc == MG_F32 && df == MG_F64) launch_prolong<float, double, double, ADD>(e, u, nxf, nyf, ldf, nxc, nyc, ldc, sides, st);
+  else if (dc == MG_F64 && df == MG_F32) launch_prolong<double, float, double, ADD>(e, u, nxf, nyf, ldf, nxc, nyc, ldc, sides, st);
+  else launch_prolong<float, float, double, ADD>(e, u, nxf, nyf, ldf, nxc, nyc, ldc, sides, st);
   return MG_OK;
+}
+template <bool ADD>
+int d_prolong(int dc, int df, int dcomp, const void* e, void* u, int nxf, int nyf, int ldf, int ldc, hipStream_t st) {
+  return d_prolong_sub<ADD>(dc, df, dcomp, e, u, nxf, nyf, ldf, (nxf - 1) / 2 + 1, (nyf - 1) / 2 + 1, ldc, mg::kAllSides, st);
 }
 void d_convert(int di, int dout, const void* in, void* out, int nx, int ny, int ldi, int ldo, hipStream_t st) {
   if (di == MG_F32 && dout == MG_F32) launch_convert<float, float>(in, out, nx, ny, ldi, ldo, st);
@@ -266,6 +279,7 @@ struct mg_handle {
   mg_config cfg;
   std::vector<Level> lv;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;   // created by mg_create; `stream` may be redirected by mg_set_stream
   double* partials = nullptr;   // device, kMaxPartials doubles
   double* d_scalar = nullptr;   // device, one double
   int* d_int = nullptr;         // device, one int (coarse sweeps)
@@ -319,7 +333,7 @@ void release(mg_handle* h) {
   if (h->staging) (void)hipFree(h->staging);
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
   if (h->h_int) (void)hipHostFree(h->h_int);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
 // ---- the cycle -----------------------------------------------------------------------------
@@ -543,7 +557,8 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
     h->lv.push_back(l);
   }
   auto bail = [&](int code) { release(h); std::string m = h->err; delete h; g_last_error = m; return code; };
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(MG_ERR_HIP); }
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(MG_ERR_HIP); }
+  h->stream = h->own_stream;
   for (int l = 0; l < h->L(); ++l) {
     Level& v = h->lv[l];
     for (int dt = 0; dt < 2; ++dt) {
@@ -601,6 +616,44 @@ int mg_level_timings(const mg_handle* h, int level, double out3[3]) {
 int mg_get_stream(mg_handle* h, void** stream) {
   if (!h || !stream) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL argument");
   *stream = (void*)h->stream;
+  return MG_OK;
+}
+
+int mg_set_stream(mg_handle* h, void* stream, int use_own) {
+  if (!h) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL handle");
+  HIPC(&h->err, hipStreamSynchronize(h->stream));
+  h->stream = use_own ? h->own_stream : (hipStream_t)stream;
+  return MG_OK;
+}
+
+int mg_set_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype) {
+  if (!h || !rhs_dev || !valid_dtype(dtype) || ld < h->lv[0].ny) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_rhs_device: bad argument");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  Level& v = h->lv[0];
+  for (int dt = 0; dt < 2; ++dt)
+    if (v.rhs[dt]) d_convert(dtype, dt, rhs_dev, v.rhs[dt], v.nx, v.ny, ld, v.ld[dt], h->stream);
+  h->have_rhs = true;
+  HIPC(&h->err, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_zero_solution_device(mg_handle* h) {
+  if (!h) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL handle");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  Level& v = h->lv[0];
+  const int dt = h->level_dtype(0);
+  HIPC(&h->err, hipMemsetAsync(v.u[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
+  if (v.t[dt]) HIPC(&h->err, hipMemsetAsync(v.t[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
+  return MG_OK;
+}
+
+int mg_get_solution_device(mg_handle* h, void* u_dev, int ld, int dtype) {
+  if (!h || !u_dev || !valid_dtype(dtype) || ld < h->lv[0].ny) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_get_solution_device: bad argument");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  Level& v = h->lv[0];
+  const int dt = h->level_dtype(0);
+  d_convert(dt, dtype, v.u[dt], u_dev, v.nx, v.ny, v.ld[dt], ld, h->stream);
+  HIPC(&h->err, hipGetLastError());
   return MG_OK;
 }
 
@@ -821,31 +874,33 @@ int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes) {
   return MG_OK;
 }
 
-int mg_dev_sumsq(int dtype, int nx, int ny, int ld, const void* field, void* scratch, double* sumsq_dev, void* stream) {
-  CHECK_DEV(valid_dtype(dtype) && nx >= 1 && ny >= 1 && ld_ok(dtype, ny, ld), "mg_dev_sumsq: bad shape / pitch");
+int mg_dev_sumsq(int dtype, int ld, int i_lo, int i_hi, int j_lo, int j_hi, const void* field, void* scratch,
+                 double* sumsq_dev, void* stream) {
+  CHECK_DEV(valid_dtype(dtype) && i_lo >= 0 && i_hi >= i_lo && j_lo >= 0 && j_hi >= j_lo && ld_ok(dtype, j_hi, ld), "mg_dev_sumsq: bad window / pitch");
   CHECK_DEV(field && scratch && sumsq_dev && aligned16(field), "mg_dev_sumsq: bad pointer");
-  const int n = d_sumsq(dtype, field, (double*)scratch, nx, ny, ld, (hipStream_t)stream);
+  const int n = d_sumsq(dtype, field, (double*)scratch, ld, i_lo, i_hi, j_lo, j_hi, (hipStream_t)stream);
   launch_reduce((double*)scratch, n, sumsq_dev, (hipStream_t)stream);
   HIPC(nullptr, hipGetLastError());
   return MG_OK;
 }
 
-int mg_dev_restrict_fw(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int ldc, const void* fine, void* coarse,
-                       void* stream) {
-  CHECK_DEV(valid_dtype(in_dtype) && valid_dtype(out_dtype) && nxf >= 3 && nyf >= 3, "mg_dev_restrict_fw: bad argument");
-  CHECK_DEV((nxf - 1) % 2 == 0 && (nyf - 1) % 2 == 0, "Cannot coarsen grid: need even number of interior points");
-  CHECK_DEV(ld_ok(in_dtype, nyf, ldf) && ld_ok(out_dtype, (nyf - 1) / 2 + 1, ldc) && fine && coarse && aligned16(coarse), "mg_dev_restrict_fw: bad pitch / pointer");
-  d_restrict(in_dtype, out_dtype, fine, coarse, nxf, nyf, ldf, ldc, (hipStream_t)stream);
+int mg_dev_restrict_fw(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides,
+                       const void* fine, void* coarse, void* stream) {
+  CHECK_DEV(valid_dtype(in_dtype) && valid_dtype(out_dtype) && nxf >= 3 && nyf >= 3 && nxc >= 2 && nyc >= 2 && sides >= 0 && sides <= 15, "mg_dev_restrict_fw: bad argument");
+  // interior coarse cells read fine rows/cols 2c-1..2c+1; a physical far edge is injected from fine 2(nc-1)
+  CHECK_DEV(2 * (nxc - 2) + 1 <= nxf - 1 && 2 * (nyc - 2) + 1 <= nyf - 1, "Cannot restrict: coarse grid too large for the fine grid");
+  CHECK_DEV((!(sides & 2) || 2 * (nxc - 1) <= nxf - 1) && (!(sides & 8) || 2 * (nyc - 1) <= nyf - 1), "Cannot restrict: coarse boundary outside the fine grid");
+  CHECK_DEV(ld_ok(in_dtype, nyf, ldf) && ld_ok(out_dtype, nyc, ldc) && fine && coarse && aligned16(coarse), "mg_dev_restrict_fw: bad pitch / pointer");
+  d_restrict_sub(in_dtype, out_dtype, fine, coarse, ldf, nxc, nyc, ldc, sides, (hipStream_t)stream);
   HIPC(nullptr, hipGetLastError());
   return MG_OK;
 }
 
-int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int nxf, int nyf, int ldf, int ldc,
-                       const void* coarse, void* fine_u, void* stream) {
-  CHECK_DEV(valid_dtype(coarse_dtype) && valid_dtype(fine_dtype) && valid_dtype(compute_dtype) && nxf >= 3 && nyf >= 3, "mg_dev_prolong_add: bad argument");
-  CHECK_DEV((nxf - 1) % 2 == 0 && (nyf - 1) % 2 == 0, "fine grid is not a refinement (2*(n-1)+1)");
-  CHECK_DEV(ld_ok(fine_dtype, nyf, ldf) && ldc >= (nyf - 1) / 2 + 1 && coarse && fine_u && aligned16(fine_u), "mg_dev_prolong_add: bad pitch / pointer");
-  const int rc = d_prolong<true>(coarse_dtype, fine_dtype, compute_dtype, coarse, fine_u, nxf, nyf, ldf, ldc, (hipStream_t)stream);
+int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int nxf, int nyf, int ldf, int nxc, int nyc,
+                       int ldc, int sides, const void* coarse, void* fine_u, void* stream) {
+  CHECK_DEV(valid_dtype(coarse_dtype) && valid_dtype(fine_dtype) && valid_dtype(compute_dtype) && nxf >= 3 && nyf >= 3 && nxc >= 2 && nyc >= 2 && sides >= 0 && sides <= 15, "mg_dev_prolong_add: bad argument");
+  CHECK_DEV(ld_ok(fine_dtype, nyf, ldf) && ldc >= nyc && coarse && fine_u && aligned16(fine_u), "mg_dev_prolong_add: bad pitch / pointer");
+  const int rc = d_prolong_sub<true>(coarse_dtype, fine_dtype, compute_dtype, coarse, fine_u, nxf, nyf, ldf, nxc, nyc, ldc, sides, (hipStream_t)stream);
   if (rc != MG_OK) return fail(nullptr, rc, "mg_dev_prolong_add: fp32 interpolation needs fp32 coarse and fine fields");
   HIPC(nullptr, hipGetLastError());
   return MG_OK;
@@ -923,7 +978,7 @@ int mg_op_norm(int dtype, int nx, int ny, double hx, double hy, const void* fiel
   RC(alloc_zero(nullptr, &part, sizeof(double) * 2048)); s.ptrs.push_back(part);
   RC(alloc_zero(nullptr, &acc, sizeof(double))); s.ptrs.push_back(acc);
   RC(up(dfld, dtype, field, nx, ny));
-  const int n = d_sumsq(dtype, dfld, (double*)part, nx, ny, pitch_elems(dtype, ny), nullptr);
+  const int n = d_sumsq(dtype, dfld, (double*)part, pitch_elems(dtype, ny), 0, nx, 0, ny, nullptr);
   launch_reduce((double*)part, n, (double*)acc, nullptr);
   double ss = 0;
   HIPC(nullptr, hipMemcpy(&ss, acc, sizeof(double), hipMemcpyDeviceToHost));

@@ -1,0 +1,498 @@
+"""Block domain decomposition of the multigrid hierarchy over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for the
+tests).  The reference has no communication backend at all (gpu/multi_gpu.py:540-607 solves
+sub-domains independently, gpu/multi_gpu_solver.py:90-185 copies slices between CuPy devices); what is
+kept from it is the partitioning idea (2-D blocks with a 1-cell overlap, gpu/multi_gpu.py:386-476,
+gpu/multi_gpu_solver.py:30-64) -- the algorithm here is the SAME V/W-cycle as the single-GPU engine,
+decomposition-invariant by construction:
+
+  * the global vertex grid (NX, NY) is cut at indices c_k = k (NX-1)/px (even on every distributed
+    level); rank (rx, ry) stores global rows c_rx .. c_rx+1 + 1: its owned cells plus a 1-cell ring
+    that is either the physical boundary or a ghost copy of the neighbour's edge.  Local cell (0,0) has
+    an even global index, so coarse cell (ic, jc) sits on local fine cell (2ic, 2jc) on every rank and
+    the red/black colouring is the global one;
+  * Jacobi / red-black GS update owned cells only (the kernels pass the ring through); every sweep
+    (every colour) is followed by a halo exchange of u; the residual gets one exchange (with corners)
+    before full-weighting restriction; prolongation interpolates the ghost ring from the exchanged
+    coarse ghost values, so no exchange is needed after the correction;
+  * below `agglomerate_at` points per direction the remaining coarse hierarchy is solved redundantly on
+    every GPU by the single-GPU engine after one all-gather of the coarse right-hand side: no broadcast
+    back, no latency-bound tiny halo messages;
+  * ||r|| is an all-reduce of one fp64 partial sum per rank over exactly the cells each rank owns.
+
+Messages are 1 row / 1 column (16-32 KB at 4097^2 per GPU): latency-bound, each neighbour pair on its
+own xGMI link.  Fields live in torch tensors (device memory, streams); the arithmetic is libmghip's
+device-pointer entry points (mg_dev_*).  `ops` and `comm` are injected so that the decomposition logic
+runs unchanged (a) on CPU under gloo with a NumPy stand-in for the kernels (tests) and (b) with several
+virtual ranks in one process on one GPU (tests), besides (c) the real thing.
+"""
+import ctypes as C
+import json
+import math
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+
+SIDE_ILO, SIDE_IHI, SIDE_JLO, SIDE_JHI = 1, 2, 4, 8
+
+
+# ------------------------------------------------------------------------------------------------
+# index bookkeeping (pure Python, no device)
+# ------------------------------------------------------------------------------------------------
+def hierarchy_shapes(nx, ny, max_levels):
+    """Global level shapes by the reference's rule (solvers/multigrid.py:153-171)."""
+    shapes = [(nx, ny)]
+    for _ in range(1, max_levels):
+        a, b = shapes[-1]
+        if (a - 1) % 2 or (b - 1) % 2:
+            break
+        c = ((a - 1) // 2 + 1, (b - 1) // 2 + 1)
+        if c[0] < 5 or c[1] < 5:
+            break
+        shapes.append(c)
+    return shapes
+
+
+def process_grid(world):
+    """px x py with px >= py, as square as possible (1, 2x1, 2x2, 4x2)."""
+    py = int(math.sqrt(world))
+    while world % py:
+        py -= 1
+    return world // py, py
+
+
+class Block:
+    """One rank's block of one level."""
+
+    def __init__(self, NX, NY, px, py, rx, ry):
+        mx, my = (NX - 1) // px, (NY - 1) // py
+        self.NX, self.NY = NX, NY
+        self.gx0, self.gy0 = rx * mx, ry * my                   # global index of local (0, 0)
+        self.lnx = mx + (1 if rx == px - 1 else 2)
+        self.lny = my + (1 if ry == py - 1 else 2)
+        self.sides = ((SIDE_ILO if rx == 0 else 0) | (SIDE_IHI if rx == px - 1 else 0) |
+                      (SIDE_JLO if ry == 0 else 0) | (SIDE_JHI if ry == py - 1 else 0))
+        # exclusive window: owned cells plus the adjacent physical boundary cells (a disjoint cover of the grid)
+        self.i_lo = 0 if rx == 0 else 1
+        self.i_hi = self.lnx if rx == px - 1 else self.lnx - 1
+        self.j_lo = 0 if ry == 0 else 1
+        self.j_hi = self.lny if ry == py - 1 else self.lny - 1
+
+
+def distributed_levels(shapes, px, py, agglomerate_at):
+    """Number of leading levels that stay distributed.  A level is distributed while its cuts are even
+    (so the next level lines up), its blocks keep >= 4 owned rows/cols and it is larger than
+    `agglomerate_at` points in some direction; at least one level is always left for the replicated part."""
+    n = 0
+    for (NX, NY) in shapes[:-1]:
+        if (NX - 1) % px or (NY - 1) % py:
+            break
+        mx, my = (NX - 1) // px, (NY - 1) // py
+        if (px > 1 and (mx % 2 or mx < 4)) or (py > 1 and (my % 2 or my < 4)):
+            break
+        if max(NX, NY) <= agglomerate_at:
+            break
+        n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels on torch tensors (device pointers into libmghip)
+# ------------------------------------------------------------------------------------------------
+class HipOps:
+    """mg_dev_* on CUDA tensors.  A field is a 2-D tensor (lnx, ld) whose first lny columns are the data."""
+
+    def __init__(self, dtype, device):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load()
+        self.np_dtype = np.dtype(dtype)
+        self.dt = _lib.dtype_code(dtype)
+        self.tdtype = torch.float32 if self.dt == _lib.MG_F32 else torch.float64
+        self.device = device
+        nbytes = C.c_int64(0)
+        _lib.check(self.lib.mg_dev_scratch_bytes(8, 8, C.byref(nbytes)))
+        self.scratch = torch.zeros(nbytes.value // 8, dtype=torch.float64, device=device)
+        self.acc = torch.zeros(1, dtype=torch.float64, device=device)
+        self._engine = None
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def alloc(self, lnx, lny):
+        ld = C.c_int(0)
+        _lib.check(self.lib.mg_pitch_elems(self.dt, lny, C.byref(ld)))
+        return self.torch.zeros((lnx, ld.value), dtype=self.tdtype, device=self.device)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def jacobi(self, u, rhs, out, lnx, lny, hx, hy, omega):
+        _lib.check(self.lib.mg_dev_jacobi(self.dt, lnx, lny, u.stride(0), hx, hy, omega, self._p(u), self._p(rhs),
+                                          self._p(out), self._stream()))
+
+    def rbgs_colour(self, u, rhs, lnx, lny, hx, hy, omega, colour, offset):
+        _lib.check(self.lib.mg_dev_rbgs_colour(self.dt, lnx, lny, u.stride(0), hx, hy, omega, colour, offset,
+                                               self._p(u), self._p(rhs), self._stream()))
+
+    def residual(self, u, f, r, lnx, lny, hx, hy, coeff):
+        _lib.check(self.lib.mg_dev_residual(self.dt, lnx, lny, u.stride(0), hx, hy, coeff, self._p(u), self._p(f),
+                                            self._p(r), self._stream()))
+
+    def sumsq(self, field, i_lo, i_hi, j_lo, j_hi):
+        """fp64 sum of squares of the window as a 1-element device tensor."""
+        _lib.check(self.lib.mg_dev_sumsq(self.dt, field.stride(0), i_lo, i_hi, j_lo, j_hi, self._p(field),
+                                         self._p(self.scratch), self._p(self.acc), self._stream()))
+        return self.acc.clone()
+
+    def restrict(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides):
+        _lib.check(self.lib.mg_dev_restrict_fw(self.dt, self.dt, lnxf, lnyf, fine.stride(0), lnxc, lnyc,
+                                               coarse.stride(0), sides, self._p(fine), self._p(coarse), self._stream()))
+
+    def prolong_add(self, coarse, fine_u, lnxf, lnyf, lnxc, lnyc, sides):
+        _lib.check(self.lib.mg_dev_prolong_add(self.dt, self.dt, self.dt, lnxf, lnyf, fine_u.stride(0), lnxc, lnyc,
+                                               coarse.stride(0), sides, self._p(coarse), self._p(fine_u), self._stream()))
+
+    # replicated coarse hierarchy = the single-GPU engine on this GPU, queued on the same stream
+    def coarse_setup(self, NX, NY, domain, cfg):
+        from .engine import MultigridEngine
+        prec = _lib.MG_PREC_SINGLE if self.dt == _lib.MG_F32 else _lib.MG_PREC_DOUBLE
+        self._engine = MultigridEngine(NX, NY, domain, cfg["coeff"], cfg["levels"], cfg["cycle"], cfg["pre"], cfg["post"],
+                                       cfg["smoother"], cfg["omega"], cfg["coarse_tol"], cfg["coarse_maxit"], prec,
+                                       device=self.device.index or 0)
+        _lib.check(self.lib.mg_set_stream(self._engine._h, self._stream(), 0))
+
+    def coarse_begin(self, rhs_global):
+        e = self._engine
+        _lib.check(self.lib.mg_set_stream(e._h, self._stream(), 0))
+        _lib.check(self.lib.mg_set_rhs_device(e._h, self._p(rhs_global), rhs_global.stride(0), self.dt))
+        _lib.check(self.lib.mg_zero_solution_device(e._h))
+
+    def coarse_cycle(self):
+        self._engine.cycle(1)
+
+    def coarse_end(self, out_global):
+        _lib.check(self.lib.mg_get_solution_device(self._engine._h, self._p(out_global), out_global.stride(0), self.dt))
+
+    def close(self):
+        if self._engine is not None:
+            self.torch.cuda.synchronize()
+            self._engine.close()
+            self._engine = None
+
+
+# ------------------------------------------------------------------------------------------------
+# the distributed driver
+# ------------------------------------------------------------------------------------------------
+class _Dom:
+    """Per-rank state: one Block per distributed level and its fields."""
+
+
+class DistributedMultigrid:
+    """V/W/F-cycle on a px x py block decomposition.
+
+    ranks:  the rank ids this PROCESS computes (one under torch.distributed; all of them for the
+            in-process virtual-rank mode used by the single-GPU test).
+    ops:    kernel provider (HipOps, or the tests' NumPy stand-in).
+    dist:   torch.distributed module (initialised) or None for the in-process mode.
+    """
+
+    def __init__(self, NX, NY, px, py, ranks, ops, dist=None, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0,
+                 max_levels=None, cycle="V", pre=2, post=2, smoother="jacobi", omega=0.8, coarse_tol=1e-12,
+                 coarse_maxit=1000, agglomerate_at=1025):
+        from .facade import default_max_levels
+        self.NX, self.NY, self.px, self.py = NX, NY, px, py
+        self.ops, self.dist = ops, dist
+        self.torch = ops.torch
+        self.domain, self.coeff = domain, coeff
+        self.cycle_type, self.pre, self.post = cycle, pre, post
+        if smoother not in ("jacobi", "rbgs"):
+            raise ValueError(f"Unknown smoother: {smoother}")
+        self.smoother, self.omega = smoother, omega
+        self.shapes = hierarchy_shapes(NX, NY, max_levels or default_max_levels(NX, NY))
+        self.L = len(self.shapes)
+        self.Ld = distributed_levels(self.shapes, px, py, agglomerate_at) if px * py > 1 else 0
+        self.h = [((domain[1] - domain[0]) / (a - 1), (domain[3] - domain[2]) / (b - 1)) for a, b in self.shapes]
+        self.ranks = list(ranks)
+        self.doms = {}
+        for r in self.ranks:
+            rx, ry = divmod(r, py)
+            d = _Dom()
+            d.rank, d.rx, d.ry = r, rx, ry
+            d.blk = [Block(a, b, px, py, rx, ry) for (a, b) in self.shapes[:self.Ld + 1]]
+            d.u, d.t, d.rhs, d.r = [], [], [], []
+            for l in range(self.Ld):
+                b = d.blk[l]
+                d.u.append(ops.alloc(b.lnx, b.lny))
+                d.t.append(ops.alloc(b.lnx, b.lny) if smoother == "jacobi" else None)
+                d.rhs.append(ops.alloc(b.lnx, b.lny))
+                d.r.append(ops.alloc(b.lnx, b.lny))
+            # the agglomeration level: a local coarse buffer (restriction target / prolongation source)
+            # and the replicated global arrays
+            if self.Ld > 0:
+                b = d.blk[self.Ld]
+                d.rc = ops.alloc(b.lnx, b.lny)
+            self.doms[r] = d
+        NXa, NYa = self.shapes[self.Ld]
+        self.rhs_a = ops.alloc(NXa, NYa)
+        self.e_a = ops.alloc(NXa, NYa)
+        smk = _lib.MG_JACOBI if smoother == "jacobi" else _lib.MG_RBGS
+        ops.coarse_setup(NXa, NYa, domain, dict(coeff=coeff, levels=self.L - self.Ld, cycle=cycle, pre=pre, post=post,
+                                                smoother=smk, omega=omega, coarse_tol=coarse_tol, coarse_maxit=coarse_maxit))
+        # gather buffers: exclusive blocks padded to the largest block
+        if self.Ld > 0:
+            b0 = Block(NXa, NYa, px, py, 0, 0)
+            self.gmx = max(Block(NXa, NYa, px, py, rx, 0).i_hi - Block(NXa, NYa, px, py, rx, 0).i_lo for rx in range(px))
+            self.gmy = max(Block(NXa, NYa, px, py, 0, ry).j_hi - Block(NXa, NYa, px, py, 0, ry).j_lo for ry in range(py))
+            del b0
+
+    # ---- neighbours ----------------------------------------------------------------------
+    def _nbr(self, d, dx, dy):
+        rx, ry = d.rx + dx, d.ry + dy
+        if 0 <= rx < self.px and 0 <= ry < self.py:
+            return rx * self.py + ry
+        return None
+
+    def _p2p(self, sends, recvs):
+        """sends/recvs: lists of (peer_rank, tensor).  Local peers are copied, remote ones go through
+        batched isend/irecv (RCCL send/recv, one group per phase)."""
+        if self.dist is None or not (sends or recvs):
+            return
+        ops = [self.dist.P2POp(self.dist.isend, t, p) for p, t in sends] + \
+              [self.dist.P2POp(self.dist.irecv, t, p) for p, t in recvs]
+        for req in self.dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def exchange(self, name, l, corners=False):
+        """Fill the ghost ring of field `name` on level l from the neighbours' owned edges.
+        Rows first, then columns over the full (ring-inclusive) height, so corners arrive too."""
+        torch = self.torch
+        fields = {r: (getattr(d, name)[l] if isinstance(getattr(d, name), list) else getattr(d, name)) for r, d in self.doms.items()}
+        # phase 1: rows (contiguous in memory: no packing)
+        sends, recvs, local = [], [], []
+        for r, d in self.doms.items():
+            b, t = d.blk[l], fields[r]
+            for dx, src_row, dst_row in ((-1, 1, 0), (+1, b.lnx - 2, b.lnx - 1)):
+                p = self._nbr(d, dx, 0)
+                if p is None:
+                    continue
+                if p in self.doms:       # neighbour lives in this process: read its owned edge directly
+                    pb = self.doms[p].blk[l]
+                    local.append((t[dst_row, :b.lny], fields[p][(pb.lnx - 2) if dx < 0 else 1, :pb.lny]))
+                else:
+                    sends.append((p, t[src_row, :b.lny]))
+                    recvs.append((p, t[dst_row, :b.lny]))
+        for dst, src in local:
+            dst.copy_(src)
+        self._p2p(sends, recvs)
+        # phase 2: columns (strided: packed into contiguous buffers)
+        sends, recvs, local, unpack = [], [], [], []
+        for r, d in self.doms.items():
+            b, t = d.blk[l], fields[r]
+            for dy, src_col, dst_col in ((-1, 1, 0), (+1, b.lny - 2, b.lny - 1)):
+                p = self._nbr(d, 0, dy)
+                if p is None:
+                    continue
+                if p in self.doms:
+                    pb = self.doms[p].blk[l]
+                    local.append((t[:b.lnx, dst_col], fields[p][:pb.lnx, (pb.lny - 2) if dy < 0 else 1]))
+                else:
+                    sbuf = t[:b.lnx, src_col].contiguous()
+                    rbuf = torch.empty_like(sbuf)
+                    sends.append((p, sbuf))
+                    recvs.append((p, rbuf))
+                    unpack.append((t[:b.lnx, dst_col], rbuf))
+        for dst, src in local:
+            dst.copy_(src)
+        self._p2p(sends, recvs)
+        for dst, src in unpack:
+            dst.copy_(src)
+
+    def allreduce_sum(self, parts):
+        """parts: {rank: 1-element fp64 tensor}.  Returns the global sum as a Python float."""
+        total = None
+        for r in self.ranks:
+            total = parts[r] if total is None else total + parts[r]
+        if self.dist is not None:
+            self.dist.all_reduce(total)
+        return float(total.item())
+
+    # ---- agglomeration -----------------------------------------------------------------------
+    def _gather_coarse_rhs(self):
+        """All ranks end up with the whole coarse right-hand side (exclusive blocks tile the grid)."""
+        torch = self.torch
+        La = self.Ld
+        NXa, NYa = self.shapes[La]
+        if self.dist is None:
+            for r, d in self.doms.items():
+                b = d.blk[La]
+                self.rhs_a[b.gx0 + b.i_lo:b.gx0 + b.i_hi, b.gy0 + b.j_lo:b.gy0 + b.j_hi] = d.rc[b.i_lo:b.i_hi, b.j_lo:b.j_hi]
+            return
+        (r, d), = self.doms.items()
+        b = d.blk[La]
+        mine = torch.zeros((self.gmx, self.gmy), dtype=d.rc.dtype, device=d.rc.device)
+        mine[:b.i_hi - b.i_lo, :b.j_hi - b.j_lo] = d.rc[b.i_lo:b.i_hi, b.j_lo:b.j_hi]
+        parts = [torch.empty_like(mine) for _ in range(self.px * self.py)]
+        self.dist.all_gather(parts, mine)
+        for q, part in enumerate(parts):
+            qb = Block(NXa, NYa, self.px, self.py, *divmod(q, self.py))
+            self.rhs_a[qb.gx0 + qb.i_lo:qb.gx0 + qb.i_hi, qb.gy0 + qb.j_lo:qb.gy0 + qb.j_hi] = \
+                part[:qb.i_hi - qb.i_lo, :qb.j_hi - qb.j_lo]
+
+    # ---- the cycle (solvers/multigrid.py:253-337) ------------------------------------------------
+    def _reps(self, l):
+        if self.cycle_type == "V":
+            return 1
+        if self.cycle_type == "W":
+            return 2
+        return max(1, 2 ** (self.L - l - 2))
+
+    def smooth(self, l, nu):
+        hx, hy = self.h[l]
+        for _ in range(nu):
+            if self.smoother == "jacobi":
+                for d in self.doms.values():
+                    b = d.blk[l]
+                    self.ops.jacobi(d.u[l], d.rhs[l], d.t[l], b.lnx, b.lny, hx, hy, self.omega)
+                    d.u[l], d.t[l] = d.t[l], d.u[l]
+                self.exchange("u", l)
+            else:
+                for colour in (0, 1):
+                    for d in self.doms.values():
+                        b = d.blk[l]
+                        self.ops.rbgs_colour(d.u[l], d.rhs[l], b.lnx, b.lny, hx, hy, self.omega, colour,
+                                             (b.gx0 + b.gy0) & 1)
+                    self.exchange("u", l)
+
+    def cycle(self, l=0):
+        if self.Ld == 0:                      # nothing distributed: the replicated engine is the whole solver
+            raise RuntimeError("single-block problems go through MultigridEngine")
+        hx, hy = self.h[l]
+        if self.pre > 0:
+            self.smooth(l, self.pre)
+        for d in self.doms.values():
+            b = d.blk[l]
+            self.ops.residual(d.u[l], d.rhs[l], d.r[l], b.lnx, b.lny, hx, hy, self.coeff)
+        self.exchange("r", l, corners=True)
+        last = (l + 1 == self.Ld)
+        for d in self.doms.values():
+            b, bc = d.blk[l], d.blk[l + 1]
+            target = d.rc if last else d.rhs[l + 1]
+            self.ops.restrict(d.r[l], target, b.lnx, b.lny, bc.lnx, bc.lny, bc.sides)
+        if last:
+            self._gather_coarse_rhs()
+            self.ops.coarse_begin(self.rhs_a)
+            for _ in range(self._reps(l)):
+                self.ops.coarse_cycle()
+            self.ops.coarse_end(self.e_a)
+            for d in self.doms.values():
+                b, bc = d.blk[l], d.blk[l + 1]
+                d.rc[:bc.lnx, :bc.lny] = self.e_a[bc.gx0:bc.gx0 + bc.lnx, bc.gy0:bc.gy0 + bc.lny]
+                self.ops.prolong_add(d.rc, d.u[l], b.lnx, b.lny, bc.lnx, bc.lny, b.sides)
+        else:
+            for d in self.doms.values():
+                d.u[l + 1].zero_()
+            for _ in range(self._reps(l)):
+                self.cycle(l + 1)
+            for d in self.doms.values():
+                b, bc = d.blk[l], d.blk[l + 1]
+                self.ops.prolong_add(d.u[l + 1], d.u[l], b.lnx, b.lny, bc.lnx, bc.lny, b.sides)
+        if self.post > 0:
+            self.smooth(l, self.post)
+
+    # ---- fields in / out -------------------------------------------------------------------------
+    def set_problem(self, rhs_of_block, u0_of_block=None):
+        """rhs_of_block(block) -> (lnx, lny) array of f on that block (ring included)."""
+        torch = self.torch
+        for d in self.doms.values():
+            b = d.blk[0]
+            d.rhs[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(rhs_of_block(b), dtype=self.ops.np_dtype)).to(d.rhs[0].device)
+            d.u[0].zero_()
+            if u0_of_block is not None:
+                d.u[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(u0_of_block(b), dtype=self.ops.np_dtype)).to(d.u[0].device)
+            if d.t[0] is not None:
+                d.t[0].copy_(d.u[0])
+
+    def residual_norm(self):
+        hx, hy = self.h[0]
+        parts = {}
+        for r, d in self.doms.items():
+            b = d.blk[0]
+            self.ops.residual(d.u[0], d.rhs[0], d.r[0], b.lnx, b.lny, hx, hy, self.coeff)
+            parts[r] = self.ops.sumsq(d.r[0], b.i_lo, b.i_hi, b.j_lo, b.j_hi)
+        return math.sqrt(hx * hy * self.allreduce_sum(parts))
+
+    def local_solution(self, rank):
+        d = self.doms[rank]
+        b = d.blk[0]
+        return b, d.u[0][:b.lnx, :b.lny].cpu().numpy()
+
+    def close(self):
+        self.ops.close()
+
+
+def sine_rhs_block(b, domain=(0.0, 1.0, 0.0, 1.0)):
+    """f = 2 pi^2 sin(pi x) sin(pi y) on one block, from GLOBAL indices (identical bits on every rank count)."""
+    hx, hy = (domain[1] - domain[0]) / (b.NX - 1), (domain[3] - domain[2]) / (b.NY - 1)
+    x = np.linspace(domain[0], domain[1], b.NX)[b.gx0:b.gx0 + b.lnx]
+    y = np.linspace(domain[2], domain[3], b.NY)[b.gy0:b.gy0 + b.lny]
+    del hx, hy
+    return 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * y)[None, :]
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py --gpus N (N > 1): weak scaling, 4097^2 points per GPU
+# ------------------------------------------------------------------------------------------------
+def bench_main(args, rank, local_rank, world):
+    import torch
+    import torch.distributed as dist
+    assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    px, py = process_grid(world)
+    m = args.n - 1
+    NX, NY = px * m + 1, py * m + 1
+    # unit cells: the domain grows with the process grid so that hx = hy = 1/(n-1) as on one GPU
+    domain = (0.0, float(px), 0.0, float(py))
+    ops = HipOps(np.float32, torch.device("cuda", local_rank))
+    solver = DistributedMultigrid(NX, NY, px, py, [rank], ops, dist, domain=domain, smoother="jacobi", omega=0.8,
+                                  cycle="V", pre=2, post=2)
+    solver.set_problem(lambda b: sine_rhs_block(b, domain))
+    K, W = args.steps, args.warmup
+    for _ in range(W):
+        solver.cycle(0)
+        solver.residual_norm()
+    solver.set_problem(lambda b: sine_rhs_block(b, domain))
+    hist = []
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        solver.cycle(0)
+        hist.append(solver.residual_norm())
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        value = NX * NY * K / dt / 1e6
+        print(json.dumps({
+            "metric": "MDoF/s per V-cycle", "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"2D Poisson {NX}x{NY} fp32, V(2,2) weighted-Jacobi omega=0.8, {px}x{py} block "
+                                   f"decomposition ({args.n}^2 per GPU), RCCL halo exchange, {solver.L} levels "
+                                   f"({solver.Ld} distributed, rest replicated after all-gather)",
+                       "grid": [NX, NY], "levels": solver.L, "cycle": "V(2,2)", "smoother": "jacobi",
+                       "parallelism": f"dd{px}x{py}"},
+            "residual_first": hist[0], "residual_last": hist[-1],
+        }))
+    solver.close()
+    dist.destroy_process_group()

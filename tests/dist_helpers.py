@@ -1,0 +1,108 @@
+"""Test infrastructure for the domain-decomposition driver: a NumPy stand-in for libmghip's device-pointer
+kernels with the SAME sub-domain semantics (ring pass-through, physical-side flags, windows), built from the
+oracle's arithmetic.  Lets the decomposition / halo / agglomeration logic run on CPU tensors under gloo."""
+import numpy as np
+import torch
+
+from oracle import mg_oracle as O
+
+SIDE_ILO, SIDE_IHI, SIDE_JLO, SIDE_JHI = 1, 2, 4, 8
+
+
+class NumpyOps:
+    def __init__(self, dtype=np.float64):
+        self.torch = torch
+        self.np_dtype = np.dtype(dtype)
+        self.tdtype = torch.float32 if self.np_dtype == np.float32 else torch.float64
+        self._mg = None
+
+    def alloc(self, lnx, lny):
+        return torch.zeros((lnx, lny + 3), dtype=self.tdtype)      # a few pad columns, like the pitched device layout
+
+    @staticmethod
+    def _v(t, lnx, lny):
+        return t.numpy()[:lnx, :lny]
+
+    def jacobi(self, u, rhs, out, lnx, lny, hx, hy, omega):
+        res = O.jacobi(self._v(u, lnx, lny), self._v(rhs, lnx, lny), hx, hy, omega, 1, "vectorized")
+        self._v(out, lnx, lny)[1:-1, 1:-1] = res[1:-1, 1:-1]       # the kernel writes owned cells only
+
+    def rbgs_colour(self, u, rhs, lnx, lny, hx, hy, omega, colour, offset):
+        a, f = self._v(u, lnx, lny), self._v(rhs, lnx, lny)
+        diag = -2.0 / hx**2 - 2.0 / hy**2
+        i = np.arange(1, lnx - 1)[:, None]; j = np.arange(1, lny - 1)[None, :]
+        m = ((i + j + offset) % 2) == colour
+        nb = (a[2:, 1:-1] + a[:-2, 1:-1]) / hx**2 + (a[1:-1, 2:] + a[1:-1, :-2]) / hy**2
+        upd = (1 - omega) * a[1:-1, 1:-1] + omega * ((f[1:-1, 1:-1] + nb) / (-diag))
+        inner = a[1:-1, 1:-1]
+        inner[m] = upd[m]
+
+    def residual(self, u, f, r, lnx, lny, hx, hy, coeff):
+        self._v(r, lnx, lny)[...] = O.residual(self._v(u, lnx, lny), self._v(f, lnx, lny), hx, hy, coeff)
+
+    def sumsq(self, field, i_lo, i_hi, j_lo, j_hi):
+        w = field.numpy()[i_lo:i_hi, j_lo:j_hi].astype(np.float64)
+        return torch.tensor([float(np.sum(w * w))], dtype=torch.float64)
+
+    def restrict(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides):
+        f, c = self._v(fine, lnxf, lnyf), self._v(coarse, lnxc, lnyc)
+        ic = np.arange(1, lnxc - 1); jc = np.arange(1, lnyc - 1)
+        I, J = np.meshgrid(2 * ic, 2 * jc, indexing="ij")
+        corners = ((f[I - 1, J - 1] + f[I - 1, J + 1]) + f[I + 1, J - 1]) + f[I + 1, J + 1]
+        edges = ((f[I - 1, J] + f[I + 1, J]) + f[I, J - 1]) + f[I, J + 1]
+        c[1:-1, 1:-1] = (1.0 / 16.0 * corners + 1.0 / 8.0 * edges) + 1.0 / 4.0 * f[I, J]
+        for cond, rows, cols in ((sides & SIDE_ILO, [0], range(lnyc)), (sides & SIDE_IHI, [lnxc - 1], range(lnyc)),
+                                 (sides & SIDE_JLO, range(lnxc), [0]), (sides & SIDE_JHI, range(lnxc), [lnyc - 1])):
+            if not cond:
+                continue
+            for a in rows:
+                for b in cols:
+                    ghost = (a == 0 and not sides & SIDE_ILO) or (a == lnxc - 1 and not sides & SIDE_IHI) or \
+                            (b == 0 and not sides & SIDE_JLO) or (b == lnyc - 1 and not sides & SIDE_JHI)
+                    if not ghost:
+                        c[a, b] = f[2 * a, 2 * b]
+
+    def prolong_add(self, coarse, fine_u, lnxf, lnyf, lnxc, lnyc, sides):
+        e, u = self._v(coarse, lnxc, lnyc), self._v(fine_u, lnxf, lnyf)
+        i = np.arange(lnxf)[:, None]; j = np.arange(lnyf)[None, :]
+        ic, io, jc, jo = i >> 1, i & 1, j >> 1, j & 1
+        valid = (ic + io < lnxc) & (jc + jo < lnyc)
+        ic1, jc1 = np.minimum(ic + 1, lnxc - 1), np.minimum(jc + 1, lnyc - 1)
+        e00, e01, e10, e11 = e[ic, jc], e[ic, jc1], e[ic1, jc], e[ic1, jc1]
+        P = np.where((io == 0) & (jo == 0), e00,
+            np.where((io == 1) & (jo == 0), 0.5 * (e00 + e10),
+            np.where((io == 0) & (jo == 1), 0.5 * (e00 + e01), 0.25 * (((e00 + e01) + e10) + e11))))
+        if sides & SIDE_JHI:
+            P = np.where((io == 1) & (jo == 0) & (j == lnyf - 1), 0.0, P)
+        if sides & SIDE_IHI:
+            P = np.where((io == 0) & (jo == 1) & (i == lnxf - 1), 0.0, P)
+        u[valid] = (u + P.astype(u.dtype))[valid]
+
+    # replicated coarse hierarchy: the oracle's single-domain cycle
+    def coarse_setup(self, NX, NY, domain, cfg):
+        kind = {0: "jacobi", 1: "rbgs"}[cfg["smoother"]]
+        self._mg = O.MGOracle(NX, NY, domain, self.np_dtype, cfg["coeff"], cfg["levels"], cfg["cycle"], cfg["pre"],
+                              cfg["post"], kind, cfg["omega"], "vectorized", cfg["coarse_tol"], cfg["coarse_maxit"])
+        self._shape = (NX, NY)
+
+    def coarse_begin(self, rhs_global):
+        self._mg.rhs[0] = self._v(rhs_global, *self._shape).copy()
+        self._e = np.zeros(self._shape, dtype=self.np_dtype)
+
+    def coarse_cycle(self):
+        self._e = self._mg.cycle_once(self._e, 0)
+
+    def coarse_end(self, out_global):
+        self._v(out_global, *self._shape)[...] = self._e
+
+    def close(self):
+        pass
+
+
+def assemble(solver, NX, NY, dtype=np.float64):
+    """Global solution from the exclusive windows of the ranks in this process."""
+    out = np.full((NX, NY), np.nan, dtype=dtype)
+    for r in solver.ranks:
+        b, u = solver.local_solution(r)
+        out[b.gx0 + b.i_lo:b.gx0 + b.i_hi, b.gy0 + b.j_lo:b.gy0 + b.j_hi] = u[b.i_lo:b.i_hi, b.j_lo:b.j_hi]
+    return out

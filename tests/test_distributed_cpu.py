@@ -1,0 +1,134 @@
+"""The N > 1 path on CPU: (a) every rank of a px x py decomposition executed in ONE process (virtual ranks,
+in-process halo copies) and (b) real multi-process runs over torch.distributed/gloo with world_size 2 and 4.
+Kernels are replaced by the NumPy stand-in of tests/dist_helpers.py; the result must equal the single-domain
+oracle BIT FOR BIT (Jacobi and globally coloured RBGS are decomposition-invariant), the norm to round-off."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from mixed_precision_multigrid_solvers_for_pdes_amd import distributed as D      # noqa: E402
+from oracle import mg_oracle as O                                                  # noqa: E402
+import dist_helpers as H                                                           # noqa: E402
+
+
+def test_block_bookkeeping():
+    assert D.process_grid(1) == (1, 1) and D.process_grid(2) == (2, 1) and D.process_grid(4) == (2, 2) and D.process_grid(8) == (4, 2)
+    b0, b1 = D.Block(8193, 4097, 2, 1, 0, 0), D.Block(8193, 4097, 2, 1, 1, 0)
+    assert (b0.gx0, b0.lnx, b0.lny, b0.sides) == (0, 4098, 4097, 1 | 4 | 8)
+    assert (b1.gx0, b1.lnx, b1.lny, b1.sides) == (4096, 4097, 4097, 2 | 4 | 8)
+    assert (b0.i_lo, b0.i_hi, b1.i_lo, b1.i_hi) == (0, 4097, 1, 4097)        # rows 0..4096 | 4097..8192: disjoint cover
+    # exclusive windows tile the grid exactly once
+    cover = np.zeros((65, 33), dtype=int)
+    for r in range(8):
+        b = D.Block(65, 33, 4, 2, *divmod(r, 2))
+        cover[b.gx0 + b.i_lo:b.gx0 + b.i_hi, b.gy0 + b.j_lo:b.gy0 + b.j_hi] += 1
+        assert b.gx0 % 2 == 0 and b.gy0 % 2 == 0
+    assert np.all(cover == 1)
+    shapes = D.hierarchy_shapes(16385, 8193, 13)
+    assert shapes[-1] == (9, 5) and D.distributed_levels(shapes, 4, 2, 1025) == 4       # 16385, 8193, 4097, 2049 stay distributed
+    shapes = D.hierarchy_shapes(8193, 8193, 12)
+    assert D.distributed_levels(shapes, 2, 2, 1025) == 3
+    assert D.distributed_levels(D.hierarchy_shapes(65, 65, 5), 2, 2, 17) == 2              # 65, 33 distributed; 17 replicated
+    assert D.distributed_levels(D.hierarchy_shapes(65, 65, 5), 2, 2, 9) == 3
+
+
+def _oracle(NX, NY, levels, cyc, kind, omega, ncycles, domain=(0.0, 1.0, 0.0, 1.0)):
+    mg = O.MGOracle(NX, NY, domain, np.float64, -1.0, levels, cyc, 2, 2, kind, omega, "vectorized")
+    rhs = _rhs(NX, NY, domain)
+    mg.rhs[0] = rhs.copy()
+    u = _u0(NX, NY)
+    hist = []
+    for _ in range(ncycles):
+        u = mg.cycle_once(u, 0)
+        hist.append(mg.residual_norm(u, rhs, 0))
+    return u, hist
+
+
+def _rhs(NX, NY, domain):
+    rng = np.random.default_rng(NX * 31 + NY)
+    return O.sine_rhs(NX, NY, domain) + 0.1 * rng.standard_normal((NX, NY))       # non-zero boundary values too
+
+
+def _u0(NX, NY):
+    rng = np.random.default_rng(NX + 7 * NY)
+    return rng.standard_normal((NX, NY))                                           # non-zero Dirichlet data + guess
+
+
+def _run_ranks(NX, NY, px, py, ranks, dist, levels, cyc, kind, omega, ncycles, agg, domain=(0.0, 1.0, 0.0, 1.0)):
+    rhs, u0 = _rhs(NX, NY, domain), _u0(NX, NY)
+    s = D.DistributedMultigrid(NX, NY, px, py, ranks, H.NumpyOps(), dist, domain=domain, max_levels=levels, cycle=cyc,
+                               smoother=kind, omega=omega, agglomerate_at=agg)
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny],
+                  lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+    hist = []
+    for _ in range(ncycles):
+        s.cycle(0)
+        hist.append(s.residual_norm())
+    return s, hist
+
+
+@pytest.mark.parametrize("px,py", [(2, 1), (1, 2), (2, 2), (4, 2)])
+@pytest.mark.parametrize("cyc,kind,omega", [("V", "jacobi", 0.8), ("W", "rbgs", 1.0), ("V", "rbgs", 1.15), ("F", "jacobi", 2 / 3)])
+def test_virtual_ranks_equal_single_domain(px, py, cyc, kind, omega):
+    NX, NY, levels = 65, 33 if py == 1 else 65, 4
+    u_ref, h_ref = _oracle(NX, NY, levels, cyc, kind, omega, 3)
+    s, hist = _run_ranks(NX, NY, px, py, range(px * py), None, levels, cyc, kind, omega, 3, agg=17)
+    assert s.Ld == 2 and s.L == levels
+    np.testing.assert_array_equal(H.assemble(s, NX, NY), u_ref)
+    np.testing.assert_allclose(hist, h_ref, rtol=1e-13)
+
+
+def test_virtual_ranks_rectangular_cells_and_single_distributed_level():
+    dom = (0.0, 2.0, 0.0, 1.0)
+    u_ref, h_ref = _oracle(129, 33, 4, "V", "jacobi", 0.8, 2, dom)
+    s, hist = _run_ranks(129, 33, 2, 1, range(2), None, 4, "V", "jacobi", 0.8, 2, agg=65, domain=dom)
+    assert s.Ld == 1
+    np.testing.assert_array_equal(H.assemble(s, 129, 33), u_ref)
+    np.testing.assert_allclose(hist, h_ref, rtol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------- gloo ----
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, px, py, cyc, kind, omega, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    NX = NY = 65
+    s, hist = _run_ranks(NX, NY, px, py, [rank], dist, 4, cyc, kind, omega, 3, agg=17)
+    b, u = s.local_solution(rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (b.gx0, b.gy0, b.i_lo, b.i_hi, b.j_lo, b.j_hi, u))
+    if rank == 0:
+        full = np.full((NX, NY), np.nan)
+        for gx0, gy0, i_lo, i_hi, j_lo, j_hi, ul in gathered:
+            full[gx0 + i_lo:gx0 + i_hi, gy0 + j_lo:gy0 + j_hi] = ul[i_lo:i_hi, j_lo:j_hi]
+        np.savez(out_path, u=full, hist=np.array(hist))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cyc,kind,omega", [(2, "V", "jacobi", 0.8), (2, "W", "rbgs", 1.0), (4, "V", "rbgs", 1.0), (4, "W", "jacobi", 0.8)])
+def test_gloo_multiprocess_equals_single_domain(tmp_path, world, cyc, kind, omega):
+    import torch.multiprocessing as mp
+    px, py = D.process_grid(world)
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), px, py, cyc, kind, omega, out), nprocs=world, join=True)
+    res = np.load(out)
+    u_ref, h_ref = _oracle(65, 65, 4, cyc, kind, omega, 3)
+    np.testing.assert_array_equal(res["u"], u_ref)
+    np.testing.assert_allclose(res["hist"], h_ref, rtol=1e-13)

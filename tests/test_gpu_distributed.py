@@ -1,0 +1,52 @@
+"""The domain-decomposition driver with the REAL kernels (libmghip device-pointer entry points) on one GPU:
+all ranks of a px x py decomposition run as virtual ranks in this process (in-process halo copies, the
+replicated coarse hierarchy on the single-GPU engine).  Must equal the single-GPU engine bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import mixed_precision_multigrid_solvers_for_pdes_amd as mg                     # noqa: E402
+from mixed_precision_multigrid_solvers_for_pdes_amd import _lib                  # noqa: E402
+from mixed_precision_multigrid_solvers_for_pdes_amd import distributed as D      # noqa: E402
+import dist_helpers as H                                                           # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("px,py,NX,NY,agg", [(2, 1, 513, 257, 65), (2, 2, 513, 513, 129), (4, 2, 1025, 513, 129), (1, 2, 257, 1025, 33)])
+@pytest.mark.parametrize("cyc,kind,omega", [("V", "jacobi", 0.8), ("W", "rbgs", 1.0)])
+def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cyc, kind, omega):
+    import torch
+    rng = np.random.default_rng(NX + NY)
+    rhs = rng.standard_normal((NX, NY)).astype(dtype)
+    u0 = rng.standard_normal((NX, NY)).astype(dtype)
+    levels = mg.default_max_levels(NX, NY)
+    ncyc = 2
+    prec = _lib.MG_PREC_SINGLE if dtype == np.float32 else _lib.MG_PREC_DOUBLE
+    eng = mg.MultigridEngine(NX, NY, max_levels=levels, cycle=cyc, smoother=_lib.MG_JACOBI if kind == "jacobi" else _lib.MG_RBGS,
+                             omega=omega, precision=prec)
+    eng.set_rhs(rhs); eng.set_solution(u0)
+    ref_hist = []
+    for _ in range(ncyc):
+        eng.cycle(1); ref_hist.append(eng.residual_norm())
+    u_ref = eng.get_solution(dtype)
+    eng.close()
+
+    ops = D.HipOps(dtype, torch.device("cuda", 0))
+    s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle=cyc, smoother=kind,
+                               omega=omega, agglomerate_at=agg)
+    assert s.Ld >= 2
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+    hist = []
+    for _ in range(ncyc):
+        s.cycle(0); hist.append(s.residual_norm())
+    u = H.assemble(s, NX, NY, dtype)
+    s.close()
+    np.testing.assert_array_equal(u, u_ref)
+    np.testing.assert_allclose(hist, ref_hist, rtol=1e-12)
