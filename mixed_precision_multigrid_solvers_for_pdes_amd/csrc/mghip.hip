@@ -313,9 +313,11 @@ struct mg_handle {
 
 namespace {
 
-int alloc_zero(std::string* err, void** p, size_t bytes) {
+// hipMemset on device memory is asynchronous to the host and runs on the NULL stream, which a
+// hipStreamNonBlocking stream does not wait for: zero on the stream that will use the memory.
+int alloc_zero(std::string* err, void** p, size_t bytes, hipStream_t st = nullptr) {
   HIPC(err, hipMalloc(p, bytes));
-  HIPC(err, hipMemset(*p, 0, bytes));
+  HIPC(err, hipMemsetAsync(*p, 0, bytes, st));
   return MG_OK;
 }
 
@@ -564,24 +566,25 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
     for (int dt = 0; dt < 2; ++dt) {
       if (!h->needs(l, dt)) continue;
       const size_t bytes = (size_t)v.nx * v.ld[dt] * esize(dt);
-      if ((rc = alloc_zero(&h->err, &v.u[dt], bytes)) != MG_OK) return bail(rc);
-      if ((rc = alloc_zero(&h->err, &v.rhs[dt], bytes)) != MG_OK) return bail(rc);
+      if ((rc = alloc_zero(&h->err, &v.u[dt], bytes, h->stream)) != MG_OK) return bail(rc);
+      if ((rc = alloc_zero(&h->err, &v.rhs[dt], bytes, h->stream)) != MG_OK) return bail(rc);
       if (l < h->L() - 1) {
-        if ((rc = alloc_zero(&h->err, &v.r[dt], bytes)) != MG_OK) return bail(rc);
-        if (cfg->smoother == MG_JACOBI && (rc = alloc_zero(&h->err, &v.t[dt], bytes)) != MG_OK) return bail(rc);
+        if ((rc = alloc_zero(&h->err, &v.r[dt], bytes, h->stream)) != MG_OK) return bail(rc);
+        if (cfg->smoother == MG_JACOBI && (rc = alloc_zero(&h->err, &v.t[dt], bytes, h->stream)) != MG_OK) return bail(rc);
       }
     }
   }
-  if ((rc = alloc_zero(&h->err, (void**)&h->partials, sizeof(double) * kMaxPartials)) != MG_OK) return bail(rc);
-  if ((rc = alloc_zero(&h->err, (void**)&h->d_scalar, sizeof(double))) != MG_OK) return bail(rc);
-  if ((rc = alloc_zero(&h->err, (void**)&h->d_int, sizeof(int))) != MG_OK) return bail(rc);
-  if ((rc = alloc_zero(&h->err, &h->staging, (size_t)cfg->nx * pitch_elems(MG_F64, cfg->ny) * 8)) != MG_OK) return bail(rc);
+  if ((rc = alloc_zero(&h->err, (void**)&h->partials, sizeof(double) * kMaxPartials, h->stream)) != MG_OK) return bail(rc);
+  if ((rc = alloc_zero(&h->err, (void**)&h->d_scalar, sizeof(double), h->stream)) != MG_OK) return bail(rc);
+  if ((rc = alloc_zero(&h->err, (void**)&h->d_int, sizeof(int), h->stream)) != MG_OK) return bail(rc);
+  if ((rc = alloc_zero(&h->err, &h->staging, (size_t)cfg->nx * pitch_elems(MG_F64, cfg->ny) * 8, h->stream)) != MG_OK) return bail(rc);
   if (hipHostMalloc((void**)&h->h_scalar, sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_int, sizeof(int)) != hipSuccess) { h->err = "hipHostMalloc failed"; return bail(MG_ERR_ALLOC); }
   {
     const mg::TileGeom g = make_geom<double>(cfg->nx, cfg->ny, h->lv[0].ld[1], false);
     if (g.ntiles > kMaxPartials) { h->err = "grid too large for the partial-sum buffer"; return bail(MG_ERR_INVALID_VALUE); }
   }
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MG_ERR_HIP); }
   *out = h;
   return MG_OK;
 }
