@@ -72,6 +72,8 @@ typedef struct mg_config {
   int32_t device;            /* HIP device ordinal                                              */
   int32_t profile;           /* 1: per-level stage timings (synchronising; solvers/multigrid.py:179-182) */
   int32_t colour_offset;     /* parity of the global index of local cell (0,0) (sub-domains)     */
+  int32_t fused;             /* 1: Jacobi cycles run as fused legs (sweeps+residual+restriction / prolongation+sweeps+norm,
+                                two launches per level, identical arithmetic); 0: one launch per operator */
 } mg_config;
 
 typedef struct mg_stats {
@@ -135,7 +137,9 @@ int mg_get_stream(mg_handle* h, void** stream);
 
 /* hipEvent-timed repetitions of one kernel of the path on the handle's own arrays and stream
  * (used by bench.py for the roofline line).  op: 0 jacobi sweep, 1 rbgs sweep (both colours),
- * 2 residual (store r), 3 residual+norm (no store), 4 restrict, 5 prolong+add, 6 whole cycle.
+ * 2 residual (store r), 3 residual+norm (no store), 4 restrict, 5 prolong+add, 6 whole cycle,
+ * 7 fused down leg (2 sweeps + residual + restriction), 8 fused up leg (prolongation + 2 sweeps [+ norm on level 0]),
+ * 9 two fused sweeps.
  * dtype selects the precision of `level`'s arrays (must be allocated under cfg.precision). */
 int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg_ms);
 

@@ -29,7 +29,7 @@ class MgConfig(C.Structure):
         ("precision", C.c_int32),
         ("switch_threshold", C.c_double), ("memory_threshold_gb", C.c_double),
         ("adaptive_reference_rule", C.c_int32),
-        ("device", C.c_int32), ("profile", C.c_int32), ("colour_offset", C.c_int32),
+        ("device", C.c_int32), ("profile", C.c_int32), ("colour_offset", C.c_int32), ("fused", C.c_int32),
     ]
 
 

@@ -223,7 +223,8 @@ __device__ __forceinline__ double wave_reduce_sum(double x) {
   return x;
 }
 
-// Sum over the block; result valid in thread 0.  `red` is >= 4 doubles of LDS.
+// Sum over the block of NW waves; result valid in thread 0.  `red` is >= NW doubles of LDS.
+template <int NW = kBlock / 64>
 __device__ __forceinline__ double block_reduce_sum(double x, double* red) {
   x = wave_reduce_sum(x);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -232,7 +233,7 @@ __device__ __forceinline__ double block_reduce_sum(double x, double* red) {
   double t = 0.0;
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+    for (int w = 0; w < NW; ++w) t += red[w];
   }
   return t;
 }
@@ -475,6 +476,227 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
     if (done) break;
   }
   if (threadIdx.x == 0 && sweeps_out) *sweeps_out = (it > maxit) ? maxit : it;
+}
+
+// ============================================================================================
+// Fused, temporally blocked smoothing stages (weighted Jacobi).
+//
+// One launch does a whole "leg" of the V-cycle on one level, so the fine arrays cross HBM once per
+// leg instead of once per operator:
+//   down leg  (POST = kPostRestrict):  nsweep Jacobi sweeps -> residual -> full-weighting restriction
+//                                      reads u, rhs; writes u', coarse rhs (interior)      3.25 w / DoF
+//   up leg    (PROLONG, POST = kPostNorm / kPostNone): u += P e -> nsweep sweeps [-> sum r^2]
+//                                      reads u, rhs, e; writes u'                           3.25 w / DoF
+//   plain     (POST = kPostNone, !PROLONG): nsweep sweeps                                    3 w / DoF
+// against (nu+1)*3w + 1.25w and 2.25w + nu*3w (+2w for the norm) when every operator is its own launch.
+//
+// A workgroup (512 threads) owns a TI x TJ tile and stages the tile plus a HALO-cell ring of u in LDS
+// (two buffers, ping-pong); every stage is evaluated on the ring too (redundantly with the neighbour
+// tiles), shrinking by one cell per stage, so the tile itself ends up exact.  Each thread keeps the rhs
+// of its fixed 3-row x 16-byte strip in registers.  Arithmetic per cell is the same sequence as in the
+// single-operator kernels, hence bit-identical results.
+//
+// Invariants the driver maintains: boundary cells of u never change and both ping-pong buffers carry
+// them; coarse-level rhs boundary cells (injection of r = f) are written once when the rhs is set.
+// ============================================================================================
+constexpr int kFusedBlock = 512;
+constexpr int kPostNone = 0, kPostRestrict = 1, kPostNorm = 2;
+
+template <typename T, int HALO> struct FusedShape {
+  static constexpr int N = VecW<T>::N;
+  static constexpr int TJ = kTileRowBytes / (int)sizeof(T);
+  static constexpr int HV = (HALO + N - 1) / N;               // halo vectors per side
+  static constexpr int RI = kTI + 2 * HALO;                   // region rows
+  static constexpr int RJ = TJ + 2 * HV * N;                  // region cols
+  static constexpr int VPR = RJ / N;                          // vectors per region row
+  static constexpr int RG = kFusedBlock / VPR;                // row groups
+  static constexpr int RPT = (RI + RG - 1) / RG;              // rows per thread
+  static constexpr int ELEMS = RI * RJ;
+};
+
+template <typename TF, typename TE, typename TC>
+__device__ __forceinline__ TF prolong_cell(const TE* __restrict__ e, int ldc, int i, int j, int nxf, int nyf, TF uval) {
+  using TS = typename std::conditional<(sizeof(TC) > sizeof(TF)), TC, TF>::type;
+  const int ic = i >> 1, jc = j >> 1;
+  const bool iodd = i & 1, jodd = j & 1;
+  const TE* r0 = e + (size_t)ic * ldc;
+  const TE* r1 = r0 + (iodd ? ldc : 0);
+  TC val;
+  if (!iodd && !jodd) {
+    val = (TC)r0[jc];
+  } else if (iodd && !jodd) {
+    val = (j == nyf - 1) ? TC(0) : TC(0.5) * ((TC)r0[jc] + (TC)r1[jc]);
+  } else if (!iodd && jodd) {
+    val = (i == nxf - 1) ? TC(0) : TC(0.5) * ((TC)r0[jc] + (TC)r0[jc + 1]);
+  } else {
+    val = TC(0.25) * ((((TC)r0[jc] + (TC)r0[jc + 1]) + (TC)r1[jc]) + (TC)r1[jc + 1]);
+  }
+  return (TF)((TS)uval + (TS)val);
+}
+
+struct FusedArgs {
+  int nx, ny, ld, nyv;          // fine level
+  int tiles_j, ntiles;
+  int nsweep;
+  int use_div;                  // 1: divide by the diagonal (1/D not exact)
+  int nxc, nyc, ldc;            // coarse level (restriction target / prolongation source)
+};
+
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG>
+__global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
+    const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
+    const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
+    TX* __restrict__ rhs_coarse,          // POST == kPostRestrict: coarse rhs (dtype TX)
+    double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 (interior cells) per block
+    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
+  using S = FusedShape<T, HALO>;
+  constexpr int N = S::N;
+  __shared__ __attribute__((aligned(16))) T bufA[S::ELEMS];
+  __shared__ __attribute__((aligned(16))) T bufB[S::ELEMS];
+  __shared__ double red[kFusedBlock / 64];
+
+  const int L = xcd_remap(blockIdx.x, a.ntiles);
+  const int ti = L / a.tiles_j, tj = L - ti * a.tiles_j;
+  const int i0 = 1 + ti * kTI, j0 = tj * S::TJ;
+  const int ri0 = i0 - HALO, rj0 = j0 - S::HV * N;           // global coords of region cell (0,0)
+  const int cv = threadIdx.x % S::VPR, rg = threadIdx.x / S::VPR;
+  const bool worker = rg < S::RG;
+  const int gj0 = rj0 + cv * N;
+  const int lc = cv * N;
+  const int r_base = rg * S::RPT;
+
+  // ---- load: rhs strip into registers, u (+ P e) into LDS --------------------------------------
+  Pack<T> f[S::RPT];
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const int r = r_base + k, gi = ri0 + r;
+    f[k] = zero_pack<T>();
+    if (!worker || r >= S::RI) continue;
+    const bool in_dom = gi >= 0 && gi < a.nx && gj0 >= 0 && gj0 < a.nyv;
+    Pack<T> uu = zero_pack<T>();
+    if (in_dom) {
+      f[k] = ldg(rhs + (size_t)gi * a.ld + gj0);
+      if (!ZERO_INIT) uu = ldg(u + (size_t)gi * a.ld + gj0);
+      if (PROLONG) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const int gj = gj0 + e;
+          if (gj < a.ny) uu.v[e] = prolong_cell<T, TX, TC>(e_coarse, a.ldc, gi, gj, a.nx, a.ny, uu.v[e]);
+        }
+      }
+    }
+    *reinterpret_cast<Pack<T>*>(bufA + r * S::RJ + lc) = uu;
+  }
+  __syncthreads();
+
+  // ---- nsweep Jacobi sweeps, ping-pong between the two LDS buffers ------------------------------
+  T* src = bufA;
+  T* dst = bufB;
+  for (int s = 0; s < a.nsweep; ++s) {
+#pragma unroll
+    for (int k = 0; k < S::RPT; ++k) {
+      const int r = r_base + k, gi = ri0 + r;
+      if (!worker || r >= S::RI) continue;
+      const Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc);
+      Pack<T> o = mid;
+      if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+        const Pack<T> up = *reinterpret_cast<const Pack<T>*>(src + (r - 1) * S::RJ + lc);
+        const Pack<T> dn = *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc);
+        const T left = src[r * S::RJ + lc - 1];
+        const T right = src[r * S::RJ + lc + N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const T w = (e == 0) ? left : mid.v[e - 1];
+          const T ea = (e == N - 1) ? right : mid.v[e + 1];
+          const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
+          const T un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
+          const T res = one_m_omega * mid.v[e] + omega * un;
+          const int gj = gj0 + e;
+          if (gj >= 1 && gj < a.ny - 1) o.v[e] = res;
+        }
+      }
+      *reinterpret_cast<Pack<T>*>(dst + r * S::RJ + lc) = o;
+    }
+    __syncthreads();
+    T* t = src; src = dst; dst = t;
+  }
+  // `src` now holds the smoothed iterate (exact on the tile and on a ring of HALO - nsweep cells)
+
+  // ---- write the tile of u' ------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const int r = r_base + k, gi = ri0 + r;
+    if (!worker || r >= S::RI) continue;
+    if (r >= HALO && r < HALO + kTI && cv >= S::HV && cv < S::HV + S::TJ / N && gi < a.nx && gj0 < a.nyv)
+      stg(out + (size_t)gi * a.ld + gj0, *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc));
+  }
+
+  if (POST == kPostNone) return;
+
+  // ---- residual on the region (r = f on boundary cells, 0 outside the grid) -------------------------
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const int r = r_base + k, gi = ri0 + r;
+    if (!worker || r >= S::RI) continue;
+    Pack<T> o = f[k];
+    if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+      const Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc);
+      const Pack<T> up = *reinterpret_cast<const Pack<T>*>(src + (r - 1) * S::RJ + lc);
+      const Pack<T> dn = *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc);
+      const T left = src[r * S::RJ + lc - 1];
+      const T right = src[r * S::RJ + lc + N];
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        const T w = (e == 0) ? left : mid.v[e - 1];
+        const T ea = (e == N - 1) ? right : mid.v[e + 1];
+        const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + w) * ihy2) - mid.v[e] * D);
+        const int gj = gj0 + e;
+        if (gj >= 1 && gj < a.ny - 1) {
+          o.v[e] = f[k].v[e] - au;
+          if (POST == kPostNorm && r >= HALO && r < HALO + kTI && cv >= S::HV && cv < S::HV + S::TJ / N)
+            acc += (double)o.v[e] * (double)o.v[e];
+        }
+      }
+    }
+    if (POST == kPostRestrict) *reinterpret_cast<Pack<T>*>(dst + r * S::RJ + lc) = o;
+  }
+
+  if (POST == kPostNorm) {
+    const double t = block_reduce_sum<kFusedBlock / 64>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    return;
+  }
+
+  // ---- full-weighting restriction of the interior coarse cells that sit on this tile ---------------
+  __syncthreads();
+  constexpr int CI = kTI / 2, CJ = S::TJ / 2;          // coarse cells per tile
+  for (int c = threadIdx.x; c < CI * CJ; c += kFusedBlock) {
+    const int ci = c / CJ, cj = c - ci * CJ;
+    const int fi = i0 + 1 + 2 * ci, fj = j0 + 2 * cj;  // i0 is odd: even fine rows are i0+1, i0+3, ...
+    const int ic = fi >> 1, jc = fj >> 1;
+    if (ic < 1 || ic > a.nxc - 2 || jc < 1 || jc > a.nyc - 2) continue;
+    const T* p = dst + (fi - ri0) * S::RJ + (fj - rj0);
+    const T corners = ((p[-S::RJ - 1] + p[-S::RJ + 1]) + p[S::RJ - 1]) + p[S::RJ + 1];
+    const T edges = ((p[-S::RJ] + p[S::RJ]) + p[-1]) + p[1];
+    rhs_coarse[(size_t)ic * a.ldc + jc] = (TX)((T(1.0 / 16.0) * corners + T(1.0 / 8.0) * edges) + T(1.0 / 4.0) * p[0]);
+  }
+}
+
+// Injection of the boundary ring fine -> coarse (the boundary part of operators/transfer.py:109-113).  With
+// r = f on boundary cells this ring of every coarse rhs is constant over a solve: written once per rhs.
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(kBlock) void inject_ring_kernel(const TIN* __restrict__ fine, TOUT* __restrict__ coarse,
+                                                             int ldf, int nxc, int nyc, int ldc) {
+  const int ring = 2 * nxc + 2 * nyc;
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < ring; t += gridDim.x * kBlock) {
+    int ic, jc;
+    if (t < nyc) { ic = 0; jc = t; }
+    else if (t < 2 * nyc) { ic = nxc - 1; jc = t - nyc; }
+    else if (t < 2 * nyc + nxc) { ic = t - 2 * nyc; jc = 0; }
+    else { ic = t - 2 * nyc - nxc; jc = nyc - 1; }
+    coarse[(size_t)ic * ldc + jc] = (TOUT)fine[(size_t)(2 * ic) * ldf + 2 * jc];
+  }
 }
 
 }  // namespace mg

@@ -231,6 +231,110 @@ void d_coarse(int dt, void* u, const void* rhs, int nx, int ny, int ld, double h
   else launch_coarse<double>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st);
 }
 
+
+// ------------------------------------------------------------------ fused legs ----------------
+template <typename T, int HALO>
+mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int nxc, int nyc, int ldc) {
+  using S = mg::FusedShape<T, HALO>;
+  mg::FusedArgs a;
+  a.nx = nx; a.ny = ny; a.ld = ld;
+  a.nyv = std::min(ld, (ny + S::N - 1) / S::N * S::N);
+  const int tiles_i = (nx - 2 + mg::kTI - 1) / mg::kTI;
+  a.tiles_j = (ny - 1 + S::TJ - 1) / S::TJ;
+  a.ntiles = tiles_i * a.tiles_j;
+  a.nsweep = nsweep; a.use_div = use_div ? 1 : 0;
+  a.nxc = nxc; a.nyc = nyc; a.ldc = ldc;
+  return a;
+}
+
+// down leg: nsweep sweeps + residual + full-weighting restriction (interior coarse cells).  TX = coarse rhs dtype.
+template <typename T, typename TX>
+void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, int nx, int ny, int ld, int nxc, int nyc, int ldc,
+                 double hx, double hy, double omega, double coeff, int nsweep, bool zero_init, bool fine, hipStream_t st) {
+  const Coef c = coefs(hx, hy);
+  const mg::FusedArgs a = fused_args<T, 4>(nx, ny, ld, nsweep, !c.pow2, nxc, nyc, ldc);
+  void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T);
+  if (zero_init) k = fine ? mg::fused_jacobi_kernel<T, 4, false, mg::kPostRestrict, true, TX, T, 1>
+                          : mg::fused_jacobi_kernel<T, 4, false, mg::kPostRestrict, true, TX, T, 0>;
+  else k = fine ? mg::fused_jacobi_kernel<T, 4, false, mg::kPostRestrict, false, TX, T, 1>
+                : mg::fused_jacobi_kernel<T, 4, false, mg::kPostRestrict, false, TX, T, 0>;
+  hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr,
+                     (TX*)rhs_c, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), (T)coeff);
+}
+
+// up leg: u += P e, nsweep sweeps, optional sum of r^2 over interior cells.  TX = coarse e dtype, TC = interpolation dtype.
+// returns the number of partials (0 without norm)
+template <typename T, typename TX, typename TC>
+int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double* partials, int nx, int ny, int ld, int nxc,
+              int nyc, int ldc, double hx, double hy, double omega, double coeff, int nsweep, bool norm, bool fine,
+              hipStream_t st) {
+  const Coef c = coefs(hx, hy);
+  if (norm) {
+    const mg::FusedArgs a = fused_args<T, 3>(nx, ny, ld, nsweep, !c.pow2, nxc, nyc, ldc);
+    auto k = fine ? mg::fused_jacobi_kernel<T, 3, true, mg::kPostNorm, false, TX, TC, 1>
+                  : mg::fused_jacobi_kernel<T, 3, true, mg::kPostNorm, false, TX, TC, 0>;
+    hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
+                       (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), (T)coeff);
+    return a.ntiles;
+  }
+  const mg::FusedArgs a = fused_args<T, 2>(nx, ny, ld, nsweep, !c.pow2, nxc, nyc, ldc);
+  auto k = fine ? mg::fused_jacobi_kernel<T, 2, true, mg::kPostNone, false, TX, TC, 1>
+                : mg::fused_jacobi_kernel<T, 2, true, mg::kPostNone, false, TX, TC, 0>;
+  hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
+                     (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), (T)coeff);
+  return 0;
+}
+
+// plain multi-sweep smoothing (nsweep <= 2 per launch)
+template <typename T>
+void launch_sweeps(const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy, double omega,
+                   int nsweep, bool fine, hipStream_t st) {
+  const Coef c = coefs(hx, hy);
+  const mg::FusedArgs a = fused_args<T, 2>(nx, ny, ld, nsweep, !c.pow2, 0, 0, 0);
+  auto k = fine ? mg::fused_jacobi_kernel<T, 2, false, mg::kPostNone, false, T, T, 1>
+                : mg::fused_jacobi_kernel<T, 2, false, mg::kPostNone, false, T, T, 0>;
+  hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr,
+                     (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), (T)0);
+}
+
+template <typename TI, typename TO>
+void launch_inject_ring(const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
+  hipLaunchKernelGGL((mg::inject_ring_kernel<TI, TO>), dim3(grid_for(2 * (nxc + nyc))), dim3(mg::kBlock), 0, st,
+                     (const TI*)fine, (TO*)coarse, ldf, nxc, nyc, ldc);
+}
+
+void d_down(int dt, int dx, const void* u, const void* rhs, void* out, void* rhs_c, int nx, int ny, int ld, int nxc, int nyc,
+            int ldc, double hx, double hy, double omega, double coeff, int nsweep, bool zero_init, bool fine, hipStream_t st) {
+  if (dt == MG_F32 && dx == MG_F32) launch_down<float, float>(u, rhs, out, rhs_c, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, zero_init, fine, st);
+  else if (dt == MG_F64 && dx == MG_F64) launch_down<double, double>(u, rhs, out, rhs_c, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, zero_init, fine, st);
+  else if (dt == MG_F64 && dx == MG_F32) launch_down<double, float>(u, rhs, out, rhs_c, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, zero_init, fine, st);
+  else launch_down<float, double>(u, rhs, out, rhs_c, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, zero_init, fine, st);
+}
+// dt: fine dtype, dx: coarse e dtype, dcomp: interpolation dtype.  Returns #partials, or -1 for an unsupported combination.
+int d_up(int dt, int dx, int dcomp, const void* u, const void* rhs, void* out, const void* e_c, double* partials, int nx,
+         int ny, int ld, int nxc, int nyc, int ldc, double hx, double hy, double omega, double coeff, int nsweep, bool norm,
+         bool fine, hipStream_t st) {
+  if (dcomp == MG_F32) {
+    if (dt == MG_F32 && dx == MG_F32) return launch_up<float, float, float>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
+    return -1;
+  }
+  if (dt == MG_F64 && dx == MG_F64) return launch_up<double, double, double>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
+  if (dt == MG_F64 && dx == MG_F32) return launch_up<double, float, double>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
+  if (dt == MG_F32 && dx == MG_F64) return launch_up<float, double, double>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
+  return launch_up<float, float, double>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
+}
+void d_sweeps(int dt, const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy, double omega,
+              int nsweep, bool fine, hipStream_t st) {
+  if (dt == MG_F32) launch_sweeps<float>(u, rhs, out, nx, ny, ld, hx, hy, omega, nsweep, fine, st);
+  else launch_sweeps<double>(u, rhs, out, nx, ny, ld, hx, hy, omega, nsweep, fine, st);
+}
+void d_inject_ring(int di, int dout, const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
+  if (di == MG_F32 && dout == MG_F32) launch_inject_ring<float, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
+  else if (di == MG_F64 && dout == MG_F64) launch_inject_ring<double, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
+  else if (di == MG_F64 && dout == MG_F32) launch_inject_ring<double, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
+  else launch_inject_ring<float, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
+}
+
 // ------------------------------------------------------------------ host <-> device helpers -----
 int upload(std::string* err, void* dev, int ddt, int ld, const void* host, int hdt, int nx, int ny, void* staging,
            hipStream_t st) {
@@ -290,21 +394,25 @@ struct mg_handle {
   int phase = MG_F64;           // working precision of the adaptive policy
   bool promoted = false;        // one-way rule: fp32 -> fp64 happened
   bool have_rhs = false;
+  double ring_sumsq[2] = {0, 0};   // sum of f^2 over the boundary ring of the fine rhs, per dtype (r = f there)
+  int norm_partials = 0;           // > 0: `partials` holds sum r^2 over interior cells of the CURRENT fine iterate
   std::string err;
   std::vector<double> adapt_hist;
 
   int L() const { return (int)lv.size(); }
   // precision a level computes in (solvers/multigrid.py:275-285 + core/precision.py:337-357); the coarsest
   // level is never converted by the reference (multigrid.py:270-272 returns first) and stays in the grid dtype.
-  int level_dtype(int l) const {
+  int level_dtype_in(int l, int ph) const {
     if (l == L() - 1) return grid_dtype;
     switch (cfg.precision) {
       case MG_PREC_SINGLE: return MG_F32;
       case MG_PREC_MIXED_LEVELS: return (l >= L() / 2) ? MG_F32 : MG_F64;
-      case MG_PREC_ADAPTIVE: return phase;
+      case MG_PREC_ADAPTIVE: return ph;
       default: return MG_F64;
     }
   }
+  int level_dtype(int l) const { return level_dtype_in(l, phase); }
+  bool fused() const { return cfg.fused != 0 && cfg.smoother == MG_JACOBI; }
   bool needs(int l, int dt) const {
     if (cfg.precision == MG_PREC_ADAPTIVE) return (l == L() - 1) ? dt == grid_dtype : true;
     return level_dtype(l) == dt;
@@ -406,9 +514,78 @@ int cycle(mg_handle* h, int l) {
   return MG_OK;
 }
 
+// Fused V/W/F-cycle: two launches per level (down leg, up leg) instead of nine.  Same arithmetic per cell.
+// zero_u: the iterate of this level is the zero correction and need not be read (first visit of a coarse level).
+int cycle_fused(mg_handle* h, int l, bool zero_u) {
+  const int L = h->L();
+  Level& f = h->lv[l];
+  const int dt = h->level_dtype(l);
+  const size_t bytes = (size_t)f.nx * f.ld[dt] * esize(dt);
+  if (l == L - 1) {
+    if (zero_u) (void)hipMemsetAsync(f.u[dt], 0, bytes, h->stream);
+    coarse_solve(h, l);
+    return MG_OK;
+  }
+  Level& c = h->lv[l + 1];
+  const int dc = h->level_dtype(l + 1);
+  const bool fine = (l == 0);
+  {
+    StageTimer tm(h, &f, 0);
+    int extra = std::max(0, h->cfg.pre - 2);
+    if (extra > 0 && zero_u) { (void)hipMemsetAsync(f.u[dt], 0, bytes, h->stream); zero_u = false; }
+    while (extra > 0) {
+      const int n = std::min(2, extra);
+      d_sweeps(dt, f.u[dt], f.rhs[dt], f.t[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.omega, n, fine, h->stream);
+      std::swap(f.u[dt], f.t[dt]);
+      extra -= n;
+    }
+    d_down(dt, dc, f.u[dt], f.rhs[dt], f.t[dt], c.rhs[dc], f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy,
+           h->cfg.omega, h->cfg.coeff, std::min(2, h->cfg.pre), zero_u, fine, h->stream);
+    std::swap(f.u[dt], f.t[dt]);
+  }
+  int reps = 1;
+  if (h->cfg.cycle == MG_CYCLE_W) reps = 2;
+  else if (h->cfg.cycle == MG_CYCLE_F) reps = std::max(1, 1 << std::max(0, L - l - 2));
+  for (int k = 0; k < reps; ++k) {
+    const int rc = cycle_fused(h, l + 1, k == 0);
+    if (rc != MG_OK) return rc;
+  }
+  {
+    StageTimer tm(h, &f, 2);
+    const bool want_norm = fine && h->cfg.post <= 2;
+    const int n = d_up(dt, dc, h->grid_dtype, f.u[dt], f.rhs[dt], f.t[dt], c.u[dc], h->partials, f.nx, f.ny, f.ld[dt],
+                       c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, std::min(2, h->cfg.post), want_norm,
+                       fine, h->stream);
+    if (n < 0) return MG_ERR_INVALID_VALUE;
+    std::swap(f.u[dt], f.t[dt]);
+    if (fine) h->norm_partials = want_norm ? n : 0;
+    int extra = std::max(0, h->cfg.post - 2);
+    while (extra > 0) {
+      const int m = std::min(2, extra);
+      d_sweeps(dt, f.u[dt], f.rhs[dt], f.t[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.omega, m, fine, h->stream);
+      std::swap(f.u[dt], f.t[dt]);
+      extra -= m;
+    }
+  }
+  return MG_OK;
+}
+
+int run_cycle(mg_handle* h) {
+  h->norm_partials = 0;
+  if (h->fused() && h->L() > 1) return cycle_fused(h, 0, false);
+  return cycle(h, 0);
+}
+
 int fine_norm(mg_handle* h, double* out) {
   Level& v = h->lv[0];
   const int dt = h->level_dtype(0);
+  if (h->norm_partials > 0 && h->ring_sumsq[dt] >= 0) {   // the up leg of the last cycle already summed r^2 over the interior cells
+    launch_reduce(h->partials, h->norm_partials, h->d_scalar, h->stream);
+    HIPC(&h->err, hipMemcpyAsync(h->h_scalar, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPC(&h->err, hipStreamSynchronize(h->stream));
+    *out = std::sqrt(v.hx * v.hy * (*h->h_scalar + h->ring_sumsq[dt]));
+    return MG_OK;
+  }
   const int n = d_residual_norm(dt, v.u[dt], v.rhs[dt], h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff,
                                 h->stream, true);
   launch_reduce(h->partials, n, h->d_scalar, h->stream);
@@ -417,6 +594,8 @@ int fine_norm(mg_handle* h, double* out) {
   *out = std::sqrt(v.hx * v.hy * *h->h_scalar);
   return MG_OK;
 }
+
+void inject_rings(mg_handle* h, int ph);
 
 // in-device cast of the fine iterate when the adaptive policy changes the working precision
 int switch_phase(mg_handle* h, int to) {
@@ -428,6 +607,8 @@ int switch_phase(mg_handle* h, int to) {
     if (v.t[to]) d_convert(from, to, v.u[from], v.t[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
   }
   h->phase = to;
+  h->norm_partials = 0;
+  if (h->have_rhs) inject_rings(h, to);
   return MG_OK;
 }
 
@@ -467,6 +648,43 @@ int adapt(mg_handle* h, double rn) {
   return switch_phase(h, to);
 }
 
+// The boundary ring of every coarse rhs is the injected fine ring (r = f on boundary cells, injection on the
+// coarse boundary: operators/laplacian.py:117-118, operators/transfer.py:109-113): constant over a solve, so it
+// is written here once per rhs (and per working precision) instead of in every cycle.
+void inject_rings(mg_handle* h, int ph) {
+  for (int l = 0; l + 1 < h->L(); ++l) {
+    Level& f = h->lv[l];
+    Level& c = h->lv[l + 1];
+    const int dt = h->level_dtype_in(l, ph), dc = h->level_dtype_in(l + 1, ph);
+    d_inject_ring(dt, dc, f.rhs[dt], c.rhs[dc], f.ld[dt], c.nx, c.ny, c.ld[dc], h->stream);
+  }
+}
+
+// sum of f^2 over the boundary ring of the fine rhs (4 windows of the device reduction), per allocated dtype
+int ring_sums(mg_handle* h) {
+  Level& v = h->lv[0];
+  for (int dt = 0; dt < 2; ++dt) {
+    h->ring_sumsq[dt] = 0;
+    if (!v.rhs[dt]) continue;
+    const int win[4][4] = {{0, 1, 0, v.ny}, {v.nx - 1, v.nx, 0, v.ny}, {1, v.nx - 1, 0, 1}, {1, v.nx - 1, v.ny - 1, v.ny}};
+    for (int k = 0; k < 4; ++k) {
+      const int n = d_sumsq(dt, v.rhs[dt], h->partials, v.ld[dt], win[k][0], win[k][1], win[k][2], win[k][3], h->stream);
+      launch_reduce(h->partials, n, h->d_scalar, h->stream);
+      HIPC(&h->err, hipMemcpyAsync(h->h_scalar, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPC(&h->err, hipStreamSynchronize(h->stream));
+      h->ring_sumsq[dt] += *h->h_scalar;
+    }
+  }
+  return MG_OK;
+}
+
+int rhs_changed(mg_handle* h) {
+  h->have_rhs = true;
+  h->norm_partials = 0;
+  inject_rings(h, h->phase);
+  return ring_sums(h);
+}
+
 int set_rhs_impl(mg_handle* h, const void* rhs, int hdt) {
   Level& v = h->lv[0];
   for (int dt = 0; dt < 2; ++dt)
@@ -474,13 +692,13 @@ int set_rhs_impl(mg_handle* h, const void* rhs, int hdt) {
       const int rc = upload(&h->err, v.rhs[dt], dt, v.ld[dt], rhs, hdt, v.nx, v.ny, h->staging, h->stream);
       if (rc != MG_OK) return rc;
     }
-  h->have_rhs = true;
-  return MG_OK;
+  return rhs_changed(h);
 }
 
 int set_u_impl(mg_handle* h, const void* u0, int hdt) {
   Level& v = h->lv[0];
   const int dt = h->level_dtype(0);
+  h->norm_partials = 0;
   if (u0) {
     int rc = upload(&h->err, v.u[dt], dt, v.ld[dt], u0, hdt, v.nx, v.ny, h->staging, h->stream);
     if (rc != MG_OK) return rc;
@@ -636,6 +854,9 @@ int mg_set_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype) {
   for (int dt = 0; dt < 2; ++dt)
     if (v.rhs[dt]) d_convert(dtype, dt, rhs_dev, v.rhs[dt], v.nx, v.ny, ld, v.ld[dt], h->stream);
   h->have_rhs = true;
+  h->norm_partials = 0;
+  inject_rings(h, h->phase);        // asynchronous; the ring sum (host round trip) is only needed by mg_residual_norm
+  h->ring_sumsq[0] = h->ring_sumsq[1] = -1.0;
   HIPC(&h->err, hipGetLastError());
   return MG_OK;
 }
@@ -643,6 +864,7 @@ int mg_set_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype) {
 int mg_zero_solution_device(mg_handle* h) {
   if (!h) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL handle");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
+  h->norm_partials = 0;
   Level& v = h->lv[0];
   const int dt = h->level_dtype(0);
   HIPC(&h->err, hipMemsetAsync(v.u[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
@@ -691,7 +913,7 @@ int mg_cycle(mg_handle* h, int ncycles) {
   if (!h->have_rhs) return fail(&h->err, MG_ERR_STATE, "mg_cycle before mg_set_rhs");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
   for (int k = 0; k < ncycles; ++k) {
-    const int rc = cycle(h, 0);
+    const int rc = run_cycle(h);
     if (rc != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
   }
   HIPC(&h->err, hipGetLastError());
@@ -735,7 +957,7 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
       ++switches;
       if (h->cfg.adaptive_reference_rule == 0) h->adapt_hist.clear();
     }
-    if ((rc = cycle(h, 0)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+    if ((rc = run_cycle(h)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
     if ((rc = fine_norm(h, &rn)) != MG_OK) return rc;         // multigrid.py:233
     h->adapt_hist.push_back(rn);
     if (it <= hist_cap) hist[it - 1] = rn;
@@ -801,8 +1023,9 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
   Level& v = h->lv[level];
   const int dt = dtype;
   if (op != 6 && (!v.u[dt] || !v.rhs[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: level has no arrays of that dtype");
-  if ((op == 0) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
-  if ((op == 2 || op == 4 || op == 5) && (level >= h->L() - 1 || !v.r[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no coarser level");
+  if ((op == 0 || op >= 7) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
+  if ((op == 2 || op == 4 || op == 5 || op == 7 || op == 8) && (level >= h->L() - 1 || !v.r[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no coarser level");
+  h->norm_partials = 0;
   hipEvent_t e0, e1;
   HIPC(&h->err, hipEventCreate(&e0));
   HIPC(&h->err, hipEventCreate(&e1));
@@ -819,7 +1042,17 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
                   d_restrict(dt, dc, v.r[dt], c.rhs[dc], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream); } break;
         case 5: { Level& c = h->lv[level + 1]; const int dc = c.u[dt] ? dt : 1 - dt;
                   if (d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], v.u[dt], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE; } break;
-        case 6: { const int rc = cycle(h, 0); if (rc != MG_OK) return rc; } break;
+        case 6: { const int rc = run_cycle(h); if (rc != MG_OK) return rc; } break;
+        case 7: { Level& c = h->lv[level + 1]; const int dc = c.rhs[dt] ? dt : 1 - dt;          // down leg
+                  d_down(dt, dc, v.u[dt], v.rhs[dt], v.t[dt], c.rhs[dc], v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy,
+                         h->cfg.omega, h->cfg.coeff, 2, false, level == 0, h->stream);
+                  std::swap(v.u[dt], v.t[dt]); } break;
+        case 8: { Level& c = h->lv[level + 1]; const int dc = c.u[dt] ? dt : 1 - dt;            // up leg (+ norm on level 0)
+                  if (d_up(dt, dc, h->grid_dtype, v.u[dt], v.rhs[dt], v.t[dt], c.u[dc], h->partials, v.nx, v.ny, v.ld[dt], c.nx, c.ny,
+                           c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, level == 0, level == 0, h->stream) < 0) return MG_ERR_INVALID_VALUE;
+                  std::swap(v.u[dt], v.t[dt]); } break;
+        case 9: d_sweeps(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, 2, level == 0, h->stream);
+                std::swap(v.u[dt], v.t[dt]); break;
         default: return MG_ERR_INVALID_VALUE;
       }
     }

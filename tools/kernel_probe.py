@@ -14,7 +14,7 @@ from mixed_precision_multigrid_solvers_for_pdes_amd import _lib      # noqa: E40
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4097
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-ops = sys.argv[3:] or ["jacobi", "residual", "residual_norm", "restrict", "prolong"]
+ops = sys.argv[3:] or ["jacobi", "sweeps2", "down_leg", "up_leg", "residual", "residual_norm", "restrict", "prolong"]
 x = np.linspace(0, 1, n)
 rhs = 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
 for smoother, names in ((_lib.MG_JACOBI, [o for o in ops if o != "rbgs"]), (_lib.MG_RBGS, [o for o in ops if o == "rbgs"])):
