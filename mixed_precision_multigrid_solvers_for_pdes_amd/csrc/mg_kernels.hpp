@@ -371,6 +371,39 @@ __global__ __launch_bounds__(kBlock) void restrict_fw_kernel(const TIN* __restri
   }
 }
 
+// Interpolated correction for the N fine cells (gi, gj0 .. gj0+N-1), gj0 even: the <= N/2+1 coarse values of
+// each of the two coarse rows are loaded once and shared by the cells (column parity is known at compile time).
+//   reference: operators/transfer.py:239-265; far-edge zeros (F9) on physical far edges (`sides`).
+template <typename TX, typename TC, int N>
+__device__ __forceinline__ void prolong_vec(const TX* __restrict__ e, int ldc, int nxc, int nyc, int gi, int gj0,
+                                            int nxf, int nyf, int sides, TC (&val)[N], bool (&ok)[N]) {
+  constexpr int M = N / 2 + 1;
+  const int ic = gi >> 1, jc0 = gj0 >> 1;
+  const bool iodd = gi & 1;
+  const bool row_ok = (ic + (iodd ? 1 : 0)) < nxc;
+  const TX* r0 = e + (size_t)ic * ldc + jc0;
+  const TX* r1 = r0 + ((iodd && row_ok) ? ldc : 0);
+  TC a[M], b[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const bool in = row_ok && (jc0 + m < nyc);
+    a[m] = in ? (TC)r0[m] : TC(0);
+    b[m] = in ? (TC)r1[m] : TC(0);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int j = gj0 + k, m = k >> 1;
+    if ((k & 1) == 0) {
+      ok[k] = row_ok && (j < nyf) && (jc0 + m < nyc);
+      val[k] = iodd ? (((sides & kSideJHi) && j == nyf - 1) ? TC(0) : TC(0.5) * (a[m] + b[m])) : a[m];
+    } else {
+      ok[k] = row_ok && (j < nyf) && (jc0 + m + 1 < nyc);
+      val[k] = iodd ? TC(0.25) * (((a[m] + a[m + 1]) + b[m]) + b[m + 1])
+                    : (((sides & kSideIHi) && gi == nxf - 1) ? TC(0) : TC(0.5) * (a[m] + a[m + 1]));
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // Bilinear prolongation fused with the correction:  u += P e   (or u = P e when ADD == false).
 //   reference: operators/transfer.py:234-267 + solvers/multigrid.py:329.  Interpolation is evaluated
@@ -391,31 +424,13 @@ __global__ __launch_bounds__(kBlock) void prolong_kernel(const TC_IN* __restrict
   for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
     const int i = (int)(v / vpr), c = (int)(v - (long long)i * vpr);
     const int j0 = c * N;
-    const int ic = i >> 1;
-    const bool iodd = i & 1;
-    if (ic + (iodd ? 1 : 0) >= nxc) continue;
-    const TC_IN* r0 = e + (size_t)ic * ldc;
-    const TC_IN* r1 = r0 + (iodd ? ldc : 0);
+    TC val[N];
+    bool ok[N];
+    prolong_vec<TC_IN, TC, N>(e, ldc, nxc, nyc, i, j0, nxf, nyf, sides, val, ok);
     Pack<TF> uo = ldg(u + (size_t)i * ldf + j0);
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const int j = j0 + k;
-      if (j >= nyf) continue;
-      const int jc = j >> 1;
-      const bool jodd = j & 1;
-      if (jc + (jodd ? 1 : 0) >= nyc) continue;
-      TC val;
-      if (!iodd && !jodd) {
-        val = (TC)r0[jc];
-      } else if (iodd && !jodd) {
-        val = ((sides & kSideJHi) && j == nyf - 1) ? TC(0) : TC(0.5) * ((TC)r0[jc] + (TC)r1[jc]);
-      } else if (!iodd && jodd) {
-        val = ((sides & kSideIHi) && i == nxf - 1) ? TC(0) : TC(0.5) * ((TC)r0[jc] + (TC)r0[jc + 1]);
-      } else {
-        val = TC(0.25) * ((((TC)r0[jc] + (TC)r0[jc + 1]) + (TC)r1[jc]) + (TC)r1[jc + 1]);
-      }
-      uo.v[k] = ADD ? (TF)((TS)uo.v[k] + (TS)val) : (TF)val;
-    }
+    for (int k = 0; k < N; ++k)
+      if (ok[k]) uo.v[k] = ADD ? (TF)((TS)uo.v[k] + (TS)val[k]) : (TF)val[k];
     stg(u + (size_t)i * ldf + j0, uo);
   }
 }
@@ -478,6 +493,59 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
   if (threadIdx.x == 0 && sweeps_out) *sweeps_out = (it > maxit) ? maxit : it;
 }
 
+
+// Small-grid variant (nx*ny <= kCoarseLdsCells): ONE wave, u and rhs live in LDS for the whole solve, the
+// stop test is a wave64 shuffle reduction.  Same arithmetic and sweep order as coarse_lexgs_kernel; the L2
+// round trip per anti-diagonal (the whole cost of a 5x5 solve) is gone.
+constexpr int kCoarseLdsCells = 1089;   // up to 33 x 33
+template <typename T>
+__global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ u, const T* __restrict__ rhs, int nx,
+                                                                int ny, int ld, T hx2, T hy2, T omega, T one_m_omega,
+                                                                T diag, T coeff, double hxhy, double tol, int maxit,
+                                                                int* __restrict__ sweeps_out) {
+  __shared__ T su[kCoarseLdsCells];
+  __shared__ T sf[kCoarseLdsCells];
+  const int lane = threadIdx.x;
+  for (int idx = lane; idx < nx * ny; idx += 64) {
+    const int i = idx / ny, j = idx - i * ny;
+    su[idx] = u[(size_t)i * ld + j];
+    sf[idx] = rhs[(size_t)i * ld + j];
+  }
+  __syncthreads();
+  int it = 0;
+  for (it = 1; it <= maxit; ++it) {
+    for (int sdiag = 2; sdiag <= nx + ny - 4; ++sdiag) {
+      const int ilo = max(1, sdiag - (ny - 2)), ihi = min(nx - 2, sdiag - 1);
+      for (int i = ilo + lane; i <= ihi; i += 64) {
+        const int j = sdiag - i;
+        T* p = su + i * ny + j;
+        const T nb = (p[ny] + p[-ny]) / hx2 + (p[1] + p[-1]) / hy2;
+        const T un = (sf[i * ny + j] + nb) / diag;
+        p[0] = one_m_omega * p[0] + omega * un;
+      }
+      __syncthreads();
+    }
+    double acc = 0.0;
+    for (int idx = lane; idx < nx * ny; idx += 64) {
+      const int i = idx / ny, j = idx - i * ny;
+      const T* p = su + idx;
+      T rv = sf[idx];
+      if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1)
+        rv = rv - coeff * (((p[ny] + p[-ny]) / hx2 + (p[1] + p[-1]) / hy2) - p[0] * diag);
+      acc += (double)rv * (double)rv;
+    }
+    acc = wave_reduce_sum(acc);
+    acc = __shfl(acc, 0, 64);
+    if (sqrt(hxhy * acc) < tol) break;
+  }
+  __syncthreads();
+  for (int idx = lane; idx < nx * ny; idx += 64) {
+    const int i = idx / ny, j = idx - i * ny;
+    if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1) u[(size_t)i * ld + j] = su[idx];
+  }
+  if (lane == 0 && sweeps_out) *sweeps_out = (it > maxit) ? maxit : it;
+}
+
 // ============================================================================================
 // Fused, temporally blocked smoothing stages (weighted Jacobi).
 //
@@ -513,26 +581,6 @@ template <typename T, int HALO> struct FusedShape {
   static constexpr int RPT = (RI + RG - 1) / RG;              // rows per thread
   static constexpr int ELEMS = RI * RJ;
 };
-
-template <typename TF, typename TE, typename TC>
-__device__ __forceinline__ TF prolong_cell(const TE* __restrict__ e, int ldc, int i, int j, int nxf, int nyf, TF uval) {
-  using TS = typename std::conditional<(sizeof(TC) > sizeof(TF)), TC, TF>::type;
-  const int ic = i >> 1, jc = j >> 1;
-  const bool iodd = i & 1, jodd = j & 1;
-  const TE* r0 = e + (size_t)ic * ldc;
-  const TE* r1 = r0 + (iodd ? ldc : 0);
-  TC val;
-  if (!iodd && !jodd) {
-    val = (TC)r0[jc];
-  } else if (iodd && !jodd) {
-    val = (j == nyf - 1) ? TC(0) : TC(0.5) * ((TC)r0[jc] + (TC)r1[jc]);
-  } else if (!iodd && jodd) {
-    val = (i == nxf - 1) ? TC(0) : TC(0.5) * ((TC)r0[jc] + (TC)r0[jc + 1]);
-  } else {
-    val = TC(0.25) * ((((TC)r0[jc] + (TC)r0[jc + 1]) + (TC)r1[jc]) + (TC)r1[jc + 1]);
-  }
-  return (TF)((TS)uval + (TS)val);
-}
 
 struct FusedArgs {
   int nx, ny, ld, nyv;          // fine level
@@ -578,11 +626,13 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
       f[k] = ldg(rhs + (size_t)gi * a.ld + gj0);
       if (!ZERO_INIT) uu = ldg(u + (size_t)gi * a.ld + gj0);
       if (PROLONG) {
+        using TS = typename std::conditional<(sizeof(TC) > sizeof(T)), TC, T>::type;
+        TC val[N];
+        bool ok[N];
+        prolong_vec<TX, TC, N>(e_coarse, a.ldc, a.nxc, a.nyc, gi, gj0, a.nx, a.ny, kAllSides, val, ok);
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-          const int gj = gj0 + e;
-          if (gj < a.ny) uu.v[e] = prolong_cell<T, TX, TC>(e_coarse, a.ldc, gi, gj, a.nx, a.ny, uu.v[e]);
-        }
+        for (int e = 0; e < N; ++e)
+          if (ok[e]) uu.v[e] = (T)((TS)uu.v[e] + (TS)val[e]);
       }
     }
     *reinterpret_cast<Pack<T>*>(bufA + r * S::RJ + lc) = uu;
@@ -640,6 +690,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
     const int r = r_base + k, gi = ri0 + r;
     if (!worker || r >= S::RI) continue;
     Pack<T> o = f[k];
+    const bool in_tile = r >= HALO && r < HALO + kTI && cv >= S::HV && cv < S::HV + S::TJ / N;
+    if (POST == kPostNorm && !in_tile) continue;        // the norm only needs r on the tile itself
     if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
       const Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc);
       const Pack<T> up = *reinterpret_cast<const Pack<T>*>(src + (r - 1) * S::RJ + lc);
@@ -654,8 +706,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
         const int gj = gj0 + e;
         if (gj >= 1 && gj < a.ny - 1) {
           o.v[e] = f[k].v[e] - au;
-          if (POST == kPostNorm && r >= HALO && r < HALO + kTI && cv >= S::HV && cv < S::HV + S::TJ / N)
-            acc += (double)o.v[e] * (double)o.v[e];
+          if (POST == kPostNorm) acc += (double)o.v[e] * (double)o.v[e];
         }
       }
     }

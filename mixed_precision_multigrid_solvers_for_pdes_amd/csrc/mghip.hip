@@ -160,6 +160,12 @@ template <typename T>
 void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff, double omega,
                    double tol, int maxit, int* sweeps_dev, hipStream_t st) {
   const Coef c = coefs(hx, hy);
+  if (nx * ny <= mg::kCoarseLdsCells) {
+    hipLaunchKernelGGL(mg::coarse_lexgs_small_kernel<T>, dim3(1), dim3(64), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
+                       (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol, maxit,
+                       sweeps_dev);
+    return;
+  }
   hipLaunchKernelGGL(mg::coarse_lexgs_kernel<T>, dim3(1), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
                      (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol,
                      maxit, sweeps_dev);
