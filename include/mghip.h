@@ -74,6 +74,8 @@ typedef struct mg_config {
   int32_t colour_offset;     /* parity of the global index of local cell (0,0) (sub-domains)     */
   int32_t fused;             /* 1: Jacobi cycles run as fused legs (sweeps+residual+restriction / prolongation+sweeps+norm,
                                 two launches per level, identical arithmetic); 0: one launch per operator */
+  int32_t tail;              /* with fused = 1 -- 1: all levels of <= ~65^2 cells incl. the coarsest solve run in ONE
+                                workgroup with their fields in LDS (one launch per visit); 0: per-level launches */
 } mg_config;
 
 typedef struct mg_stats {

@@ -502,13 +502,13 @@ template <typename T>
 __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ u, const T* __restrict__ rhs, int nx,
                                                                 int ny, int ld, T hx2, T hy2, T omega, T one_m_omega,
                                                                 T diag, T coeff, double hxhy, double tol, int maxit,
-                                                                int* __restrict__ sweeps_out) {
+                                                                int* __restrict__ sweeps_out, int zero_init) {
   __shared__ T su[kCoarseLdsCells];
   __shared__ T sf[kCoarseLdsCells];
   const int lane = threadIdx.x;
   for (int idx = lane; idx < nx * ny; idx += 64) {
     const int i = idx / ny, j = idx - i * ny;
-    su[idx] = u[(size_t)i * ld + j];
+    su[idx] = zero_init ? T(0) : u[(size_t)i * ld + j];      // zero_init: the zero correction, ring included
     sf[idx] = rhs[(size_t)i * ld + j];
   }
   __syncthreads();
@@ -544,6 +544,200 @@ __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ 
     if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1) u[(size_t)i * ld + j] = su[idx];
   }
   if (lane == 0 && sweeps_out) *sweeps_out = (it > maxit) ? maxit : it;
+}
+
+// ============================================================================================
+// Coarse tail: every level with <= ~65^2 cells, down to and including the coarsest-grid solve, runs in ONE
+// workgroup with all of its fields resident in LDS (137 KB for 65^2..5^2 in fp64).  A V-cycle visits those
+// levels with ~12 launches of ~5 us each (launch-latency floor); a W-cycle visits the coarsest one 2^(L-1)
+// times.  Here the whole sub-cycle is one launch that interprets a host-built schedule of
+// {down leg, coarsest solve, up leg} steps.  Arithmetic per cell is identical to the per-operator kernels.
+// ============================================================================================
+constexpr int kTailBlock = 1024;
+constexpr int kTailMaxLevels = 6;
+constexpr int kTailDown = 0, kTailSolve = 1, kTailUp = 2;
+
+struct TailLevel {
+  int nx, ny;
+  int off;                     // byte offset of this level's arrays in the LDS pool
+  double ihx2, ihy2, invD, diag, hx2, hy2, hxhy;
+  int use_div;
+};
+struct TailArgs {
+  int nlev, nops, pre, post, ld_top, maxit;
+  double omega, coeff, tol;
+  TailLevel lv[kTailMaxLevels];
+};
+
+template <typename T>
+__device__ __forceinline__ void tail_sweep(const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ f,
+                                           const TailLevel& L, T omega, T one_m_omega) {
+  const T ihx2 = (T)L.ihx2, ihy2 = (T)L.ihy2, invD = (T)L.invD, D = (T)L.diag;
+  const int ny = L.ny, ni = L.nx - 2, nj = ny - 2;
+  for (int c = threadIdx.x; c < ni * nj; c += kTailBlock) {
+    const int i = 1 + c / nj, j = 1 + c % nj, idx = i * ny + j;
+    const T nb = ihx2 * (src[idx + ny] + src[idx - ny]) + ihy2 * (src[idx + 1] + src[idx - 1]);
+    const T un = L.use_div ? (f[idx] + nb) / D : (f[idx] + nb) * invD;
+    dst[idx] = one_m_omega * src[idx] + omega * un;
+  }
+}
+
+template <typename T, typename TCO, typename TC>
+__global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __restrict__ rhs_top, T* __restrict__ u_top,
+                                                                 const int* __restrict__ ops, TailArgs a, int zero_top,
+                                                                 int* __restrict__ sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pool[];
+  const int last = a.nlev - 1;
+  const T omega = (T)a.omega, one_m_omega = (T)(1.0 - a.omega), coeff = (T)a.coeff;
+  // per level: two iterate buffers (ping-pong) and the rhs; the last level holds {u, rhs} in TCO
+  auto Ubuf = [&](int l, int which) -> T* { return reinterpret_cast<T*>(pool + a.lv[l].off) + (size_t)which * a.lv[l].nx * a.lv[l].ny; };
+  auto Fbuf = [&](int l) -> T* { return reinterpret_cast<T*>(pool + a.lv[l].off) + (size_t)2 * a.lv[l].nx * a.lv[l].ny; };
+  TCO* const Ulast = reinterpret_cast<TCO*>(pool + a.lv[last].off);
+  TCO* const Flast = Ulast + a.lv[last].nx * a.lv[last].ny;
+
+  {   // zero the pool (rings of every iterate buffer stay zero for the whole launch), then load the top level
+    const int words = (a.lv[last].off + 2 * a.lv[last].nx * a.lv[last].ny * (int)sizeof(TCO) + 3) / 4;
+    int* w = reinterpret_cast<int*>(pool);
+    for (int c = threadIdx.x; c < words; c += kTailBlock) w[c] = 0;
+  }
+  __syncthreads();
+  {
+    const TailLevel& L0 = a.lv[0];
+    T* f0 = Fbuf(0);
+    T* u0 = Ubuf(0, 0);
+    for (int c = threadIdx.x; c < L0.nx * L0.ny; c += kTailBlock) {
+      const int i = c / L0.ny, j = c - i * L0.ny;
+      f0[c] = rhs_top[(size_t)i * a.ld_top + j];
+      if (!zero_top && i >= 1 && i < L0.nx - 1 && j >= 1 && j < L0.ny - 1) u0[c] = u_top[(size_t)i * a.ld_top + j];
+    }
+  }
+  __syncthreads();
+
+  unsigned cur = 0;   // bit l: which iterate buffer of level l is current
+  for (int ip = 0; ip < a.nops; ++ip) {
+    const int op = ops[ip];
+    const int code = op & 0xff, l = (op >> 8) & 0xff, zflag = (op >> 16) & 0xff;
+    const bool zero = (zflag == 2) ? (zero_top != 0) : (zflag != 0);
+    if (code == kTailDown) {
+      const TailLevel& L = a.lv[l];
+      const int ny = L.ny, ni = L.nx - 2, nj = ny - 2;
+      if (zero && l > 0) {          // the zero correction (l == 0 was loaded / zeroed at entry)
+        T* u = Ubuf(l, (cur >> l) & 1);
+        for (int c = threadIdx.x; c < ni * nj; c += kTailBlock) u[(1 + c / nj) * ny + 1 + c % nj] = T(0);
+        __syncthreads();
+      }
+      for (int s = 0; s < a.pre; ++s) {
+        tail_sweep<T>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega);
+        cur ^= (1u << l);
+        __syncthreads();
+      }
+      // residual of interior cells into the non-current buffer (its ring is never touched)
+      const T* u = Ubuf(l, (cur >> l) & 1);
+      T* r = Ubuf(l, ((cur >> l) & 1) ^ 1);
+      const T* f = Fbuf(l);
+      {
+        const T ihx2 = (T)L.ihx2, ihy2 = (T)L.ihy2, D = (T)L.diag;
+        for (int c = threadIdx.x; c < ni * nj; c += kTailBlock) {
+          const int idx = (1 + c / nj) * ny + 1 + c % nj;
+          const T au = coeff * (((u[idx + ny] + u[idx - ny]) * ihx2 + (u[idx + 1] + u[idx - 1]) * ihy2) - u[idx] * D);
+          r[idx] = f[idx] - au;
+        }
+      }
+      __syncthreads();
+      // full weighting into the next level's rhs; coarse boundary = injection of r = f
+      const TailLevel& Lc = a.lv[l + 1];
+      for (int c = threadIdx.x; c < Lc.nx * Lc.ny; c += kTailBlock) {
+        const int ic = c / Lc.ny, jc = c - ic * Lc.ny;
+        const int fidx = (2 * ic) * ny + 2 * jc;
+        T val;
+        if (ic == 0 || ic == Lc.nx - 1 || jc == 0 || jc == Lc.ny - 1) {
+          val = f[fidx];
+        } else {
+          const T* p = r + fidx;
+          const T corners = ((p[-ny - 1] + p[-ny + 1]) + p[ny - 1]) + p[ny + 1];
+          const T edges = ((p[-ny] + p[ny]) + p[-1]) + p[1];
+          val = (T(1.0 / 16.0) * corners + T(1.0 / 8.0) * edges) + T(1.0 / 4.0) * p[0];
+        }
+        if (l + 1 == last) Flast[c] = (TCO)val; else Fbuf(l + 1)[c] = val;
+      }
+      __syncthreads();
+    } else if (code == kTailSolve) {
+      // coarsest level: lexicographic GS by ONE wave (anti-diagonal order, wave-level sync only)
+      if (threadIdx.x < 64) {
+        const TailLevel& L = a.lv[last];
+        const int nx = L.nx, ny = L.ny, lane = threadIdx.x;
+        volatile TCO* su = Ulast;
+        const volatile TCO* sf = Flast;
+        const TCO hx2 = (TCO)L.hx2, hy2 = (TCO)L.hy2, diag = (TCO)L.diag, cf = (TCO)a.coeff;
+        if (zero) {
+          for (int c = lane; c < nx * ny; c += 64) su[c] = TCO(0);
+          __builtin_amdgcn_wave_barrier();
+        }
+        int it = 0;
+        for (it = 1; it <= a.maxit; ++it) {
+          for (int sdiag = 2; sdiag <= nx + ny - 4; ++sdiag) {
+            const int ilo = max(1, sdiag - (ny - 2)), ihi = min(nx - 2, sdiag - 1);
+            for (int i = ilo + lane; i <= ihi; i += 64) {
+              const int idx = i * ny + (sdiag - i);
+              const TCO nb = (su[idx + ny] + su[idx - ny]) / hx2 + (su[idx + 1] + su[idx - 1]) / hy2;
+              const TCO un = (sf[idx] + nb) / diag;
+              su[idx] = TCO(0) * su[idx] + TCO(1) * un;      // omega = 1: (1-w)*u + w*un, as the reference evaluates it
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+          double acc = 0.0;
+          for (int c = lane; c < nx * ny; c += 64) {
+            const int i = c / ny, j = c - i * ny;
+            TCO rv = sf[c];
+            if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1)
+              rv = rv - cf * (((su[c + ny] + su[c - ny]) / hx2 + (su[c + 1] + su[c - 1]) / hy2) - su[c] * diag);
+            acc += (double)rv * (double)rv;
+          }
+          acc = wave_reduce_sum(acc);
+          acc = __shfl(acc, 0, 64);
+          if (sqrt(L.hxhy * acc) < a.tol) break;
+        }
+        if (lane == 0 && sweeps_out) *sweeps_out = (it > a.maxit) ? a.maxit : it;
+      }
+      __syncthreads();
+    } else {   // kTailUp: u_l += P u_{l+1}, then the post sweeps
+      using TS = typename std::conditional<(sizeof(TC) > sizeof(T)), TC, T>::type;
+      const TailLevel& L = a.lv[l];
+      const TailLevel& Lc = a.lv[l + 1];
+      const int nx = L.nx, ny = L.ny, nyc = Lc.ny;
+      T* u = Ubuf(l, (cur >> l) & 1);
+      const T* ec = (l + 1 == last) ? nullptr : Ubuf(l + 1, (cur >> (l + 1)) & 1);
+      for (int c = threadIdx.x; c < nx * ny; c += kTailBlock) {
+        const int i = c / ny, j = c - i * ny;
+        const int ic = i >> 1, jc = j >> 1;
+        const bool iodd = i & 1, jodd = j & 1;
+        const int b0 = ic * nyc + jc, b1 = b0 + (iodd ? nyc : 0);
+        TC e00, e01, e10, e11;
+        if (l + 1 == last) { e00 = (TC)Ulast[b0]; e01 = jodd ? (TC)Ulast[b0 + 1] : e00; e10 = (TC)Ulast[b1]; e11 = jodd ? (TC)Ulast[b1 + 1] : e10; }
+        else { e00 = (TC)ec[b0]; e01 = jodd ? (TC)ec[b0 + 1] : e00; e10 = (TC)ec[b1]; e11 = jodd ? (TC)ec[b1 + 1] : e10; }
+        TC val;
+        if (!iodd && !jodd) val = e00;
+        else if (iodd && !jodd) val = (j == ny - 1) ? TC(0) : TC(0.5) * (e00 + e10);
+        else if (!iodd && jodd) val = (i == nx - 1) ? TC(0) : TC(0.5) * (e00 + e01);
+        else val = TC(0.25) * (((e00 + e01) + e10) + e11);
+        u[c] = (T)((TS)u[c] + (TS)val);
+      }
+      __syncthreads();
+      for (int s = 0; s < a.post; ++s) {
+        tail_sweep<T>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega);
+        cur ^= (1u << l);
+        __syncthreads();
+      }
+    }
+  }
+  {   // the correction of the top level back to HBM (interior cells; the ring is zero and stays zero there)
+    const TailLevel& L0 = a.lv[0];
+    const T* u0 = Ubuf(0, cur & 1);
+    for (int c = threadIdx.x; c < L0.nx * L0.ny; c += kTailBlock) {
+      const int i = c / L0.ny, j = c - i * L0.ny;
+      if (i >= 1 && i < L0.nx - 1 && j >= 1 && j < L0.ny - 1) u_top[(size_t)i * a.ld_top + j] = u0[c];
+    }
+  }
 }
 
 // ============================================================================================

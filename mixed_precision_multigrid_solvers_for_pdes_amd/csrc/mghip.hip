@@ -158,14 +158,15 @@ void launch_convert(const void* in, void* out, int nx, int ny, int ldi, int ldo,
 
 template <typename T>
 void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff, double omega,
-                   double tol, int maxit, int* sweeps_dev, hipStream_t st) {
+                   double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false) {
   const Coef c = coefs(hx, hy);
   if (nx * ny <= mg::kCoarseLdsCells) {
     hipLaunchKernelGGL(mg::coarse_lexgs_small_kernel<T>, dim3(1), dim3(64), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
                        (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol, maxit,
-                       sweeps_dev);
+                       sweeps_dev, zero_init ? 1 : 0);
     return;
   }
+  if (zero_init) (void)hipMemsetAsync(u, 0, (size_t)nx * ld * sizeof(T), st);
   hipLaunchKernelGGL(mg::coarse_lexgs_kernel<T>, dim3(1), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
                      (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol,
                      maxit, sweeps_dev);
@@ -232,9 +233,9 @@ void d_convert(int di, int dout, const void* in, void* out, int nx, int ny, int 
   else launch_convert<float, double>(in, out, nx, ny, ldi, ldo, st);
 }
 void d_coarse(int dt, void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff,
-              double omega, double tol, int maxit, int* sweeps_dev, hipStream_t st) {
-  if (dt == MG_F32) launch_coarse<float>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st);
-  else launch_coarse<double>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st);
+              double omega, double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false) {
+  if (dt == MG_F32) launch_coarse<float>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init);
+  else launch_coarse<double>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init);
 }
 
 
@@ -402,6 +403,9 @@ struct mg_handle {
   bool have_rhs = false;
   double ring_sumsq[2] = {0, 0};   // sum of f^2 over the boundary ring of the fine rhs, per dtype (r = f there)
   int norm_partials = 0;           // > 0: `partials` holds sum r^2 over interior cells of the CURRENT fine iterate
+  int tail_start = -1;             // first level of the single-workgroup LDS tail (-1: none)
+  int* d_tail_ops = nullptr;       // device copy of the tail schedule
+  int tail_nops = 0;
   std::string err;
   std::vector<double> adapt_hist;
 
@@ -443,6 +447,7 @@ void release(mg_handle* h) {
       if (l.rhs[d]) (void)hipFree(l.rhs[d]);
       if (l.r[d]) (void)hipFree(l.r[d]);
     }
+  if (h->d_tail_ops) (void)hipFree(h->d_tail_ops);
   if (h->partials) (void)hipFree(h->partials);
   if (h->d_scalar) (void)hipFree(h->d_scalar);
   if (h->d_int) (void)hipFree(h->d_int);
@@ -483,12 +488,12 @@ void smooth(mg_handle* h, int l, int nu) {
   }
 }
 
-void coarse_solve(mg_handle* h, int l) {
+void coarse_solve(mg_handle* h, int l, bool zero_init = false) {
   Level& v = h->lv[l];
   const int dt = h->level_dtype(l);
   // solvers/multigrid.py:119-124: the default coarse solver is GaussSeidelSmoother(omega = 1)
   d_coarse(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, 1.0, h->cfg.coarse_tol,
-           h->cfg.coarse_maxit, h->d_int, h->stream);
+           h->cfg.coarse_maxit, h->d_int, h->stream, zero_init);
 }
 
 int cycle(mg_handle* h, int l) {
@@ -520,6 +525,100 @@ int cycle(mg_handle* h, int l) {
   return MG_OK;
 }
 
+
+// ------------------------------------------------------------------ coarse tail (one workgroup, LDS) ----
+constexpr size_t kTailPoolLimit = 150 * 1024;
+
+size_t tail_pool_bytes(const mg_handle* h, int k, size_t esz, size_t esz_last) {
+  size_t b = 0;
+  for (int l = k; l < h->L(); ++l) {
+    const size_t cells = (size_t)h->lv[l].nx * h->lv[l].ny;
+    b += (l == h->L() - 1) ? 2 * cells * esz_last : 3 * cells * esz;
+    b = (b + 15) / 16 * 16;
+  }
+  return b;
+}
+
+void tail_schedule(const mg_handle* h, int k, int l, int zero_flag, std::vector<int>& ops) {
+  const int L = h->L();
+  if (l == L - 1) { ops.push_back(mg::kTailSolve | ((l - k) << 8) | (zero_flag << 16)); return; }
+  ops.push_back(mg::kTailDown | ((l - k) << 8) | (zero_flag << 16));
+  int reps = 1;
+  if (h->cfg.cycle == MG_CYCLE_W) reps = 2;
+  else if (h->cfg.cycle == MG_CYCLE_F) reps = std::max(1, 1 << std::max(0, L - l - 2));
+  for (int r = 0; r < reps; ++r) tail_schedule(h, k, l + 1, r == 0 ? 1 : 0, ops);
+  ops.push_back(mg::kTailUp | ((l - k) << 8));
+}
+
+template <typename T, typename TCO, typename TC>
+int tail_set_attr(size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&mg::coarse_tail_kernel<T, TCO, TC>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? MG_OK : MG_ERR_HIP;
+}
+
+// Decide where the tail starts: the first level k >= 1 whose sub-hierarchy fits the LDS pool, has at most
+// kTailMaxLevels levels and (per-level MIXED policy) one dtype on levels k .. L-2.
+int plan_tail(mg_handle* h) {
+  h->tail_start = -1;
+  const int L = h->L();
+  if (!h->fused() || L < 3 || h->cfg.pre > 8 || h->cfg.post > 8) return MG_OK;
+  const size_t esz_last = esize(h->grid_dtype);
+  for (int k = 1; k <= L - 2; ++k) {
+    if (L - k > mg::kTailMaxLevels) continue;
+    const size_t esz = (h->cfg.precision == MG_PREC_ADAPTIVE) ? 8 : esize(h->level_dtype_in(k, MG_F64));
+    if (tail_pool_bytes(h, k, esz, esz_last) > kTailPoolLimit) continue;
+    bool uniform = true;
+    for (int l = k; l <= L - 2; ++l) uniform = uniform && (h->level_dtype_in(l, MG_F64) == h->level_dtype_in(k, MG_F64));
+    if (!uniform) continue;
+    h->tail_start = k;
+    break;
+  }
+  if (h->tail_start < 0) return MG_OK;
+  std::vector<int> ops;
+  tail_schedule(h, h->tail_start, h->tail_start, 2, ops);
+  h->tail_nops = (int)ops.size();
+  HIPC(&h->err, hipMalloc((void**)&h->d_tail_ops, sizeof(int) * ops.size()));
+  HIPC(&h->err, hipMemcpy(h->d_tail_ops, ops.data(), sizeof(int) * ops.size(), hipMemcpyHostToDevice));
+  const size_t lim = kTailPoolLimit + 1024;
+  if (tail_set_attr<double, double, double>(lim) != MG_OK || tail_set_attr<float, float, float>(lim) != MG_OK ||
+      tail_set_attr<float, double, double>(lim) != MG_OK) { h->tail_start = -1; }
+  return MG_OK;
+}
+
+int launch_tail(mg_handle* h, bool zero_top) {
+  const int k = h->tail_start, L = h->L();
+  const int dt = h->level_dtype(k), dco = h->grid_dtype;
+  mg::TailArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.nlev = L - k; a.nops = h->tail_nops; a.pre = h->cfg.pre; a.post = h->cfg.post;
+  a.ld_top = h->lv[k].ld[dt]; a.maxit = h->cfg.coarse_maxit;
+  a.omega = h->cfg.omega; a.coeff = h->cfg.coeff; a.tol = h->cfg.coarse_tol;
+  size_t off = 0;
+  for (int l = k; l < L; ++l) {
+    const Level& v = h->lv[l];
+    mg::TailLevel& t = a.lv[l - k];
+    const Coef c = coefs(v.hx, v.hy);
+    t.nx = v.nx; t.ny = v.ny; t.off = (int)off;
+    t.ihx2 = c.ihx2; t.ihy2 = c.ihy2; t.invD = c.invD; t.diag = c.diag; t.hx2 = v.hx * v.hx; t.hy2 = v.hy * v.hy;
+    t.hxhy = v.hx * v.hy; t.use_div = c.pow2 ? 0 : 1;
+    const size_t cells = (size_t)v.nx * v.ny;
+    off += (l == L - 1) ? 2 * cells * esize(dco) : 3 * cells * esize(dt);
+    off = (off + 15) / 16 * 16;
+  }
+  Level& top = h->lv[k];
+  const dim3 grid(1), block(mg::kTailBlock);
+  if (dt == MG_F64)
+    hipLaunchKernelGGL((mg::coarse_tail_kernel<double, double, double>), grid, block, off, h->stream, (const double*)top.rhs[dt],
+                       (double*)top.u[dt], h->d_tail_ops, a, zero_top ? 1 : 0, h->d_int);
+  else if (dco == MG_F32)
+    hipLaunchKernelGGL((mg::coarse_tail_kernel<float, float, float>), grid, block, off, h->stream, (const float*)top.rhs[dt],
+                       (float*)top.u[dt], h->d_tail_ops, a, zero_top ? 1 : 0, h->d_int);
+  else
+    hipLaunchKernelGGL((mg::coarse_tail_kernel<float, double, double>), grid, block, off, h->stream, (const float*)top.rhs[dt],
+                       (float*)top.u[dt], h->d_tail_ops, a, zero_top ? 1 : 0, h->d_int);
+  return MG_OK;
+}
+
 // Fused V/W/F-cycle: two launches per level (down leg, up leg) instead of nine.  Same arithmetic per cell.
 // zero_u: the iterate of this level is the zero correction and need not be read (first visit of a coarse level).
 int cycle_fused(mg_handle* h, int l, bool zero_u) {
@@ -527,9 +626,9 @@ int cycle_fused(mg_handle* h, int l, bool zero_u) {
   Level& f = h->lv[l];
   const int dt = h->level_dtype(l);
   const size_t bytes = (size_t)f.nx * f.ld[dt] * esize(dt);
+  if (l == h->tail_start && h->cfg.tail != 0) return launch_tail(h, zero_u);
   if (l == L - 1) {
-    if (zero_u) (void)hipMemsetAsync(f.u[dt], 0, bytes, h->stream);
-    coarse_solve(h, l);
+    coarse_solve(h, l, zero_u);
     return MG_OK;
   }
   Level& c = h->lv[l + 1];
@@ -808,6 +907,7 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
     const mg::TileGeom g = make_geom<double>(cfg->nx, cfg->ny, h->lv[0].ld[1], false);
     if (g.ntiles > kMaxPartials) { h->err = "grid too large for the partial-sum buffer"; return bail(MG_ERR_INVALID_VALUE); }
   }
+  if ((rc = plan_tail(h)) != MG_OK) return bail(rc);
   if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MG_ERR_HIP); }
   *out = h;
   return MG_OK;

@@ -172,14 +172,16 @@ def test_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post):
     rhs = O.sine_rhs(nx, ny) + 0.05 * rng.standard_normal((nx, ny))
     u0 = rng.standard_normal((nx, ny))
     res = []
-    for fused in (True, False):
+    for fused, tail in ((True, True), (True, False), (False, False)):
         eng = mg.MultigridEngine(nx, ny, max_levels=mg.default_max_levels(nx, ny), cycle=cyc, pre=pre, post=post,
                                  smoother=_lib.MG_JACOBI, omega=0.8, precision=code, switch_threshold=1e-3,
-                                 coarse_maxit=60, fused=fused)
+                                 coarse_maxit=60, fused=fused, tail=tail)
         u, r = eng.solve(rhs, u0, tol=1e-30, max_iterations=6)
         eng.close()
         res.append((u, r))
-    (uf, rf), (uu, ru) = res
+    (ut, rt), (uf, rf), (uu, ru) = res
     np.testing.assert_array_equal(uf, uu)
+    np.testing.assert_array_equal(ut, uu)
     np.testing.assert_allclose(rf["residual_history"], ru["residual_history"], rtol=1e-11)
-    assert rf["precision_codes"] == ru["precision_codes"]
+    np.testing.assert_allclose(rt["residual_history"], ru["residual_history"], rtol=1e-11)
+    assert rf["precision_codes"] == ru["precision_codes"] == rt["precision_codes"]
