@@ -502,7 +502,10 @@ template <typename T>
 __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ u, const T* __restrict__ rhs, int nx,
                                                                 int ny, int ld, T hx2, T hy2, T omega, T one_m_omega,
                                                                 T diag, T coeff, double hxhy, double tol, int maxit,
-                                                                int* __restrict__ sweeps_out, int zero_init) {
+                                                                int* __restrict__ sweeps_out, int zero_init, int exact_recip) {
+  // exact_recip: hx^2, hy^2 and the diagonal are powers of two, so x / c == x * (1/c) bit for bit and the
+  // three IEEE divisions per cell (the reference divides, solvers/smoothers.py:165-170) become multiplications.
+  const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
   __shared__ T su[kCoarseLdsCells];
   __shared__ T sf[kCoarseLdsCells];
   const int lane = threadIdx.x;
@@ -519,8 +522,10 @@ __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ 
       for (int i = ilo + lane; i <= ihi; i += 64) {
         const int j = sdiag - i;
         T* p = su + i * ny + j;
-        const T nb = (p[ny] + p[-ny]) / hx2 + (p[1] + p[-1]) / hy2;
-        const T un = (sf[i * ny + j] + nb) / diag;
+        const T sx = p[ny] + p[-ny], sy = p[1] + p[-1];
+        const T nb = exact_recip ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
+        const T num = sf[i * ny + j] + nb;
+        const T un = exact_recip ? num * rdiag : num / diag;
         p[0] = one_m_omega * p[0] + omega * un;
       }
       __syncthreads();
@@ -530,8 +535,10 @@ __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ 
       const int i = idx / ny, j = idx - i * ny;
       const T* p = su + idx;
       T rv = sf[idx];
-      if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1)
-        rv = rv - coeff * (((p[ny] + p[-ny]) / hx2 + (p[1] + p[-1]) / hy2) - p[0] * diag);
+      if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1) {
+        const T sx = p[ny] + p[-ny], sy = p[1] + p[-1];
+        rv = rv - coeff * ((exact_recip ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - p[0] * diag);
+      }
       acc += (double)rv * (double)rv;
     }
     acc = wave_reduce_sum(acc);
@@ -562,6 +569,7 @@ struct TailLevel {
   int off;                     // byte offset of this level's arrays in the LDS pool
   double ihx2, ihy2, invD, diag, hx2, hy2, hxhy;
   int use_div;
+  int exact_recip;             // hx^2, hy^2 and the diagonal are all powers of two
 };
 struct TailArgs {
   int nlev, nops, pre, post, ld_top, maxit;
@@ -596,9 +604,9 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
   TCO* const Flast = Ulast + a.lv[last].nx * a.lv[last].ny;
 
   {   // zero the pool (rings of every iterate buffer stay zero for the whole launch), then load the top level
-    const int words = (a.lv[last].off + 2 * a.lv[last].nx * a.lv[last].ny * (int)sizeof(TCO) + 3) / 4;
-    int* w = reinterpret_cast<int*>(pool);
-    for (int c = threadIdx.x; c < words; c += kTailBlock) w[c] = 0;
+    const int quads = (a.lv[last].off + 2 * a.lv[last].nx * a.lv[last].ny * (int)sizeof(TCO) + 15) / 16;
+    int4* w = reinterpret_cast<int4*>(pool);
+    for (int c = threadIdx.x; c < quads; c += kTailBlock) w[c] = make_int4(0, 0, 0, 0);
   }
   __syncthreads();
   {
@@ -669,6 +677,8 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
         volatile TCO* su = Ulast;
         const volatile TCO* sf = Flast;
         const TCO hx2 = (TCO)L.hx2, hy2 = (TCO)L.hy2, diag = (TCO)L.diag, cf = (TCO)a.coeff;
+        const TCO rhx2 = TCO(1) / hx2, rhy2 = TCO(1) / hy2, rdiag = TCO(1) / diag;
+        const bool exact = L.exact_recip != 0;      // powers of two: x / c == x * (1/c) bit for bit
         if (zero) {
           for (int c = lane; c < nx * ny; c += 64) su[c] = TCO(0);
           __builtin_amdgcn_wave_barrier();
@@ -679,8 +689,10 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
             const int ilo = max(1, sdiag - (ny - 2)), ihi = min(nx - 2, sdiag - 1);
             for (int i = ilo + lane; i <= ihi; i += 64) {
               const int idx = i * ny + (sdiag - i);
-              const TCO nb = (su[idx + ny] + su[idx - ny]) / hx2 + (su[idx + 1] + su[idx - 1]) / hy2;
-              const TCO un = (sf[idx] + nb) / diag;
+              const TCO sx = su[idx + ny] + su[idx - ny], sy = su[idx + 1] + su[idx - 1];
+              const TCO nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
+              const TCO num = sf[idx] + nb;
+              const TCO un = exact ? num * rdiag : num / diag;
               su[idx] = TCO(0) * su[idx] + TCO(1) * un;      // omega = 1: (1-w)*u + w*un, as the reference evaluates it
             }
             __builtin_amdgcn_wave_barrier();
@@ -689,8 +701,10 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
           for (int c = lane; c < nx * ny; c += 64) {
             const int i = c / ny, j = c - i * ny;
             TCO rv = sf[c];
-            if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1)
-              rv = rv - cf * (((su[c + ny] + su[c - ny]) / hx2 + (su[c + 1] + su[c - 1]) / hy2) - su[c] * diag);
+            if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1) {
+              const TCO sx = su[c + ny] + su[c - ny], sy = su[c + 1] + su[c - 1];
+              rv = rv - cf * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - su[c] * diag);
+            }
             acc += (double)rv * (double)rv;
           }
           acc = wave_reduce_sum(acc);

@@ -66,7 +66,8 @@ mg::TileGeom make_geom(int nx, int ny, int ld, bool interior_only) {
 
 struct Coef {
   double ihx2, ihy2, diag, invD;
-  bool pow2;   // 1/diag is exact: multiply instead of divide
+  bool pow2;       // 1/diag is exact: multiply instead of divide
+  bool all_pow2;   // hx^2, hy^2 and diag are all powers of two
 };
 inline Coef coefs(double hx, double hy) {
   Coef c;
@@ -76,6 +77,7 @@ inline Coef coefs(double hx, double hy) {
   c.invD = 1.0 / c.diag;
   int e = 0;
   c.pow2 = std::frexp(c.diag, &e) == 0.5;
+  c.all_pow2 = c.pow2 && std::frexp(hx * hx, &e) == 0.5 && std::frexp(hy * hy, &e) == 0.5;
   return c;
 }
 
@@ -163,7 +165,7 @@ void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, 
   if (nx * ny <= mg::kCoarseLdsCells) {
     hipLaunchKernelGGL(mg::coarse_lexgs_small_kernel<T>, dim3(1), dim3(64), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
                        (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol, maxit,
-                       sweeps_dev, zero_init ? 1 : 0);
+                       sweeps_dev, zero_init ? 1 : 0, c.all_pow2 ? 1 : 0);
     return;
   }
   if (zero_init) (void)hipMemsetAsync(u, 0, (size_t)nx * ld * sizeof(T), st);
@@ -600,7 +602,7 @@ int launch_tail(mg_handle* h, bool zero_top) {
     const Coef c = coefs(v.hx, v.hy);
     t.nx = v.nx; t.ny = v.ny; t.off = (int)off;
     t.ihx2 = c.ihx2; t.ihy2 = c.ihy2; t.invD = c.invD; t.diag = c.diag; t.hx2 = v.hx * v.hx; t.hy2 = v.hy * v.hy;
-    t.hxhy = v.hx * v.hy; t.use_div = c.pow2 ? 0 : 1;
+    t.hxhy = v.hx * v.hy; t.use_div = c.pow2 ? 0 : 1; t.exact_recip = c.all_pow2 ? 1 : 0;
     const size_t cells = (size_t)v.nx * v.ny;
     off += (l == L - 1) ? 2 * cells * esize(dco) : 3 * cells * esize(dt);
     off = (off + 15) / 16 * 16;
