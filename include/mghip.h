@@ -46,7 +46,10 @@ typedef enum {
   MG_PREC_DOUBLE = 0,       /* Grid(dtype=float64), no precision manager                       */
   MG_PREC_SINGLE = 1,       /* Grid(dtype=float32)                                             */
   MG_PREC_MIXED_LEVELS = 2, /* PrecisionManager('mixed'): level >= L//2 fp32 (core/precision.py:337-357) */
-  MG_PREC_ADAPTIVE = 3      /* threshold switch fp32 <-> fp64 (core/precision.py:270-302)      */
+  MG_PREC_ADAPTIVE = 3,     /* threshold switch fp32 <-> fp64 (core/precision.py:270-302)      */
+  MG_PREC_SINGLE_MANAGED = 4/* PrecisionManager('single', adaptive=False) on a float64 Grid: every level converted to
+                               fp32 on entry (solvers/multigrid.py:281-285) except the coarsest, which the reference never
+                               converts (:270-272) and solves in fp64; interpolation in fp64 (operators/transfer.py:207) */
 } mg_precision_t;
 
 /* Packed solver configuration: the constructor kwargs of MultigridSolver

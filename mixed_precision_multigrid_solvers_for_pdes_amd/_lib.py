@@ -12,7 +12,7 @@ MG_ERR_INVALID_VALUE, MG_ERR_NO_DEVICE, MG_ERR_HIP, MG_ERR_STATE, MG_ERR_ALLOC =
 MG_F32, MG_F64 = 0, 1
 MG_JACOBI, MG_RBGS, MG_LEXGS = 0, 1, 2
 MG_CYCLE_V, MG_CYCLE_W, MG_CYCLE_F = 0, 1, 2
-MG_PREC_DOUBLE, MG_PREC_SINGLE, MG_PREC_MIXED_LEVELS, MG_PREC_ADAPTIVE = 0, 1, 2, 3
+MG_PREC_DOUBLE, MG_PREC_SINGLE, MG_PREC_MIXED_LEVELS, MG_PREC_ADAPTIVE, MG_PREC_SINGLE_MANAGED = 0, 1, 2, 3, 4
 
 CYCLES = {"V": MG_CYCLE_V, "W": MG_CYCLE_W, "F": MG_CYCLE_F}
 

@@ -318,14 +318,30 @@ __global__ __launch_bounds__(kBlock) void sumsq_kernel(const T* __restrict__ x, 
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// Host-visible mailbox for one scalar: the kernel stores the value, fences at system scope, then stores the
+// sequence number; the host spins on `seq` (pinned, coherent host memory) instead of paying a stream
+// synchronisation per multigrid iteration.
+struct HostMailbox {
+  double value;
+  unsigned long long seq;
+};
+
 // Fixed-order final reduction of the per-block partials (deterministic, one block).
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials, int n,
-                                                                 double* __restrict__ out) {
+                                                                 double* __restrict__ out, HostMailbox* mailbox,
+                                                                 unsigned long long seq) {
   __shared__ double red[kBlock / 64];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += kBlock) acc += partials[i];
   const double t = block_reduce_sum(acc, red);
-  if (threadIdx.x == 0) *out = t;
+  if (threadIdx.x == 0) {
+    *out = t;
+    if (mailbox) {
+      mailbox->value = t;
+      __threadfence_system();
+      __hip_atomic_store(&mailbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -848,32 +864,38 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   __syncthreads();
 
   // ---- nsweep Jacobi sweeps, ping-pong between the two LDS buffers ------------------------------
+  // A thread's RPT rows are consecutive: the row above / current / below slide through registers, so a sweep
+  // reads RPT + 2 row vectors (not 3 RPT) plus the two lateral scalars per row.
   T* src = bufA;
   T* dst = bufB;
   for (int s = 0; s < a.nsweep; ++s) {
+    if (worker && r_base < S::RI) {
+      Pack<T> up = (r_base >= 1) ? *reinterpret_cast<const Pack<T>*>(src + (r_base - 1) * S::RJ + lc) : zero_pack<T>();
+      Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r_base * S::RJ + lc);
 #pragma unroll
-    for (int k = 0; k < S::RPT; ++k) {
-      const int r = r_base + k, gi = ri0 + r;
-      if (!worker || r >= S::RI) continue;
-      const Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc);
-      Pack<T> o = mid;
-      if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
-        const Pack<T> up = *reinterpret_cast<const Pack<T>*>(src + (r - 1) * S::RJ + lc);
-        const Pack<T> dn = *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc);
-        const T left = src[r * S::RJ + lc - 1];
-        const T right = src[r * S::RJ + lc + N];
+      for (int k = 0; k < S::RPT; ++k) {
+        const int r = r_base + k, gi = ri0 + r;
+        if (r >= S::RI) break;
+        const Pack<T> dn = (r + 1 < S::RI) ? *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc) : zero_pack<T>();
+        Pack<T> o = mid;
+        if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+          const T left = src[r * S::RJ + lc - 1];
+          const T right = src[r * S::RJ + lc + N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-          const T w = (e == 0) ? left : mid.v[e - 1];
-          const T ea = (e == N - 1) ? right : mid.v[e + 1];
-          const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
-          const T un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
-          const T res = one_m_omega * mid.v[e] + omega * un;
-          const int gj = gj0 + e;
-          if (gj >= 1 && gj < a.ny - 1) o.v[e] = res;
+          for (int e = 0; e < N; ++e) {
+            const T w = (e == 0) ? left : mid.v[e - 1];
+            const T ea = (e == N - 1) ? right : mid.v[e + 1];
+            const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
+            const T un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
+            const T res = one_m_omega * mid.v[e] + omega * un;
+            const int gj = gj0 + e;
+            if (gj >= 1 && gj < a.ny - 1) o.v[e] = res;
+          }
         }
+        *reinterpret_cast<Pack<T>*>(dst + r * S::RJ + lc) = o;
+        up = mid;
+        mid = dn;
       }
-      *reinterpret_cast<Pack<T>*>(dst + r * S::RJ + lc) = o;
     }
     __syncthreads();
     T* t = src; src = dst; dst = t;
@@ -893,32 +915,36 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
 
   // ---- residual on the region (r = f on boundary cells, 0 outside the grid) -------------------------
   double acc = 0.0;
+  if (worker && r_base < S::RI) {
+    Pack<T> up = (r_base >= 1) ? *reinterpret_cast<const Pack<T>*>(src + (r_base - 1) * S::RJ + lc) : zero_pack<T>();
+    Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r_base * S::RJ + lc);
 #pragma unroll
-  for (int k = 0; k < S::RPT; ++k) {
-    const int r = r_base + k, gi = ri0 + r;
-    if (!worker || r >= S::RI) continue;
-    Pack<T> o = f[k];
-    const bool in_tile = r >= HALO && r < HALO + kTI && cv >= S::HV && cv < S::HV + S::TJ / N;
-    if (POST == kPostNorm && !in_tile) continue;        // the norm only needs r on the tile itself
-    if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
-      const Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc);
-      const Pack<T> up = *reinterpret_cast<const Pack<T>*>(src + (r - 1) * S::RJ + lc);
-      const Pack<T> dn = *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc);
-      const T left = src[r * S::RJ + lc - 1];
-      const T right = src[r * S::RJ + lc + N];
+    for (int k = 0; k < S::RPT; ++k) {
+      const int r = r_base + k, gi = ri0 + r;
+      if (r >= S::RI) break;
+      const Pack<T> dn = (r + 1 < S::RI) ? *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc) : zero_pack<T>();
+      Pack<T> o = f[k];
+      const bool in_tile = r >= HALO && r < HALO + kTI && cv >= S::HV && cv < S::HV + S::TJ / N;
+      const bool wanted = (POST == kPostRestrict) || in_tile;      // the norm only needs r on the tile itself
+      if (wanted && r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+        const T left = src[r * S::RJ + lc - 1];
+        const T right = src[r * S::RJ + lc + N];
 #pragma unroll
-      for (int e = 0; e < N; ++e) {
-        const T w = (e == 0) ? left : mid.v[e - 1];
-        const T ea = (e == N - 1) ? right : mid.v[e + 1];
-        const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + w) * ihy2) - mid.v[e] * D);
-        const int gj = gj0 + e;
-        if (gj >= 1 && gj < a.ny - 1) {
-          o.v[e] = f[k].v[e] - au;
-          if (POST == kPostNorm) acc += (double)o.v[e] * (double)o.v[e];
+        for (int e = 0; e < N; ++e) {
+          const T w = (e == 0) ? left : mid.v[e - 1];
+          const T ea = (e == N - 1) ? right : mid.v[e + 1];
+          const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + w) * ihy2) - mid.v[e] * D);
+          const int gj = gj0 + e;
+          if (gj >= 1 && gj < a.ny - 1) {
+            o.v[e] = f[k].v[e] - au;
+            if (POST == kPostNorm) acc += (double)o.v[e] * (double)o.v[e];
+          }
         }
       }
+      if (POST == kPostRestrict) *reinterpret_cast<Pack<T>*>(dst + r * S::RJ + lc) = o;
+      up = mid;
+      mid = dn;
     }
-    if (POST == kPostRestrict) *reinterpret_cast<Pack<T>*>(dst + r * S::RJ + lc) = o;
   }
 
   if (POST == kPostNorm) {

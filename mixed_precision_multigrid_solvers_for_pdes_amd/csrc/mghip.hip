@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -133,8 +134,9 @@ int launch_sumsq(const void* x, double* partials, int ld, int i_lo, int i_hi, in
   return nb;
 }
 
-inline void launch_reduce(const double* partials, int n, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(mg::reduce_partials_kernel, dim3(1), dim3(mg::kBlock), 0, st, partials, n, out);
+inline void launch_reduce(const double* partials, int n, double* out, hipStream_t st, mg::HostMailbox* mailbox = nullptr,
+                          unsigned long long seq = 0) {
+  hipLaunchKernelGGL(mg::reduce_partials_kernel, dim3(1), dim3(mg::kBlock), 0, st, partials, n, out, mailbox, seq);
 }
 
 template <typename TI, typename TO>
@@ -398,6 +400,9 @@ struct mg_handle {
   int* d_int = nullptr;         // device, one int (coarse sweeps)
   double* h_scalar = nullptr;   // pinned host
   int* h_int = nullptr;         // pinned host
+  mg::HostMailbox* mbox = nullptr;       // pinned, mapped: the norm of every iteration arrives here
+  mg::HostMailbox* mbox_dev = nullptr;   // its device-side address
+  unsigned long long mbox_seq = 0;
   void* staging = nullptr;      // fine-level sized fp64 staging for dtype-converting transfers
   int grid_dtype = MG_F64;      // the reference Grid's dtype: MG_F32 only for MG_PREC_SINGLE
   int phase = MG_F64;           // working precision of the adaptive policy
@@ -418,6 +423,7 @@ struct mg_handle {
     if (l == L() - 1) return grid_dtype;
     switch (cfg.precision) {
       case MG_PREC_SINGLE: return MG_F32;
+      case MG_PREC_SINGLE_MANAGED: return MG_F32;
       case MG_PREC_MIXED_LEVELS: return (l >= L() / 2) ? MG_F32 : MG_F64;
       case MG_PREC_ADAPTIVE: return ph;
       default: return MG_F64;
@@ -454,6 +460,7 @@ void release(mg_handle* h) {
   if (h->d_scalar) (void)hipFree(h->d_scalar);
   if (h->d_int) (void)hipFree(h->d_int);
   if (h->staging) (void)hipFree(h->staging);
+  if (h->mbox) (void)hipHostFree(h->mbox);
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
   if (h->h_int) (void)hipHostFree(h->h_int);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -683,22 +690,52 @@ int run_cycle(mg_handle* h) {
   return cycle(h, 0);
 }
 
+// Reduce `n` partial sums and bring the scalar to the host.  Fast path: the kernel posts it to the mapped
+// mailbox and the host spins on the sequence number (a few microseconds after the kernel retires); if nothing
+// arrives within 2 s, or there is no mailbox, fall back to copy + stream synchronisation.
+int reduce_to_host(mg_handle* h, int n, double* value) {
+  if (h->mbox_dev) {
+    const unsigned long long seq = ++h->mbox_seq;
+    launch_reduce(h->partials, n, h->d_scalar, h->stream, h->mbox_dev, seq);
+    HIPC(&h->err, hipGetLastError());
+    volatile unsigned long long* flag = &h->mbox->seq;
+    const double t0 = now_s();
+    long spins = 0;
+    while (*flag != seq) {
+      if ((++spins & 0x3fff) == 0 && now_s() - t0 > 2.0) break;
+    }
+    if (*flag == seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      *value = *(volatile double*)&h->mbox->value;
+      return MG_OK;
+    }
+    HIPC(&h->err, hipStreamSynchronize(h->stream));     // slow or faulted device: this reports the error, if any
+    if (*flag == seq) { *value = *(volatile double*)&h->mbox->value; return MG_OK; }
+  } else {
+    launch_reduce(h->partials, n, h->d_scalar, h->stream);
+  }
+  HIPC(&h->err, hipMemcpyAsync(h->h_scalar, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPC(&h->err, hipStreamSynchronize(h->stream));
+  *value = *h->h_scalar;
+  return MG_OK;
+}
+
 int fine_norm(mg_handle* h, double* out) {
   Level& v = h->lv[0];
   const int dt = h->level_dtype(0);
   if (h->norm_partials > 0 && h->ring_sumsq[dt] >= 0) {   // the up leg of the last cycle already summed r^2 over the interior cells
-    launch_reduce(h->partials, h->norm_partials, h->d_scalar, h->stream);
-    HIPC(&h->err, hipMemcpyAsync(h->h_scalar, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPC(&h->err, hipStreamSynchronize(h->stream));
-    *out = std::sqrt(v.hx * v.hy * (*h->h_scalar + h->ring_sumsq[dt]));
+    double ss = 0;
+    const int rc = reduce_to_host(h, h->norm_partials, &ss);
+    if (rc != MG_OK) return rc;
+    *out = std::sqrt(v.hx * v.hy * (ss + h->ring_sumsq[dt]));
     return MG_OK;
   }
   const int n = d_residual_norm(dt, v.u[dt], v.rhs[dt], h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff,
                                 h->stream, true);
-  launch_reduce(h->partials, n, h->d_scalar, h->stream);
-  HIPC(&h->err, hipMemcpyAsync(h->h_scalar, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPC(&h->err, hipStreamSynchronize(h->stream));
-  *out = std::sqrt(v.hx * v.hy * *h->h_scalar);
+  double ss = 0;
+  const int rc = reduce_to_host(h, n, &ss);
+  if (rc != MG_OK) return rc;
+  *out = std::sqrt(v.hx * v.hy * ss);
   return MG_OK;
 }
 
@@ -851,7 +888,7 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
     return fail(nullptr, MG_ERR_INVALID_VALUE, "Grid must have at least 3 points in each direction");   // core/grid.py:34-35
   if (cfg->cycle < MG_CYCLE_V || cfg->cycle > MG_CYCLE_F) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown cycle type");
   if (cfg->smoother < MG_JACOBI || cfg->smoother > MG_LEXGS) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown smoother");
-  if (cfg->precision < MG_PREC_DOUBLE || cfg->precision > MG_PREC_ADAPTIVE) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown precision policy");
+  if (cfg->precision < MG_PREC_DOUBLE || cfg->precision > MG_PREC_SINGLE_MANAGED) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown precision policy");
   if (cfg->pre < 0 || cfg->post < 0 || cfg->max_levels < 1 || cfg->coarse_maxit < 1)
     return fail(nullptr, MG_ERR_INVALID_VALUE, "negative sweep count / max_levels < 1 / coarse_maxit < 1");
   if (!(cfg->x1 > cfg->x0) || !(cfg->y1 > cfg->y0)) return fail(nullptr, MG_ERR_INVALID_VALUE, "empty domain");
@@ -905,6 +942,12 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
   if ((rc = alloc_zero(&h->err, &h->staging, (size_t)cfg->nx * pitch_elems(MG_F64, cfg->ny) * 8, h->stream)) != MG_OK) return bail(rc);
   if (hipHostMalloc((void**)&h->h_scalar, sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_int, sizeof(int)) != hipSuccess) { h->err = "hipHostMalloc failed"; return bail(MG_ERR_ALLOC); }
+  if (hipHostMalloc((void**)&h->mbox, sizeof(mg::HostMailbox), hipHostMallocMapped) == hipSuccess &&
+      hipHostGetDevicePointer((void**)&h->mbox_dev, h->mbox, 0) == hipSuccess) {
+    h->mbox->value = 0; h->mbox->seq = 0;
+  } else {
+    h->mbox_dev = nullptr;     // no mapped host memory: fall back to copy + stream synchronisation
+  }
   {
     const mg::TileGeom g = make_geom<double>(cfg->nx, cfg->ny, h->lv[0].ld[1], false);
     if (g.ntiles > kMaxPartials) { h->err = "grid too large for the partial-sum buffer"; return bail(MG_ERR_INVALID_VALUE); }

@@ -106,12 +106,17 @@ def distributed_levels(shapes, px, py, agglomerate_at):
 class HipOps:
     """mg_dev_* on CUDA tensors.  A field is a 2-D tensor (lnx, ld) whose first lny columns are the data."""
 
-    def __init__(self, dtype, device):
+    def __init__(self, dtype, device, managed_single=False):
+        """managed_single (fp32 fields only): the reference's PrecisionManager('single') layout on a float64 Grid --
+        interpolation in fp64 and the coarsest level solved in fp64 (otherwise an fp32 coarsest solve can never
+        meet the 1e-12 tolerance and burns its 1000 sweeps on every visit, exactly like Grid(dtype=float32) does)."""
         import torch
         self.torch = torch
         self.lib = _lib.load()
         self.np_dtype = np.dtype(dtype)
         self.dt = _lib.dtype_code(dtype)
+        self.managed = bool(managed_single) and self.dt == _lib.MG_F32
+        self.comp_dt = _lib.MG_F64 if self.managed else self.dt
         self.tdtype = torch.float32 if self.dt == _lib.MG_F32 else torch.float64
         self.device = device
         nbytes = C.c_int64(0)
@@ -155,13 +160,13 @@ class HipOps:
                                                coarse.stride(0), sides, self._p(fine), self._p(coarse), self._stream()))
 
     def prolong_add(self, coarse, fine_u, lnxf, lnyf, lnxc, lnyc, sides):
-        _lib.check(self.lib.mg_dev_prolong_add(self.dt, self.dt, self.dt, lnxf, lnyf, fine_u.stride(0), lnxc, lnyc,
+        _lib.check(self.lib.mg_dev_prolong_add(self.dt, self.dt, self.comp_dt, lnxf, lnyf, fine_u.stride(0), lnxc, lnyc,
                                                coarse.stride(0), sides, self._p(coarse), self._p(fine_u), self._stream()))
 
     # replicated coarse hierarchy = the single-GPU engine on this GPU, queued on the same stream
     def coarse_setup(self, NX, NY, domain, cfg):
         from .engine import MultigridEngine
-        prec = _lib.MG_PREC_SINGLE if self.dt == _lib.MG_F32 else _lib.MG_PREC_DOUBLE
+        prec = (_lib.MG_PREC_SINGLE_MANAGED if self.managed else _lib.MG_PREC_SINGLE) if self.dt == _lib.MG_F32 else _lib.MG_PREC_DOUBLE
         self._engine = MultigridEngine(NX, NY, domain, cfg["coeff"], cfg["levels"], cfg["cycle"], cfg["pre"], cfg["post"],
                                        cfg["smoother"], cfg["omega"], cfg["coarse_tol"], cfg["coarse_maxit"], prec,
                                        device=self.device.index or 0)
@@ -459,7 +464,7 @@ def bench_main(args, rank, local_rank, world):
     NX, NY = px * m + 1, py * m + 1
     # unit cells: the domain grows with the process grid so that hx = hy = 1/(n-1) as on one GPU
     domain = (0.0, float(px), 0.0, float(py))
-    ops = HipOps(np.float32, torch.device("cuda", local_rank))
+    ops = HipOps(np.float32, torch.device("cuda", local_rank), managed_single=True)
     solver = DistributedMultigrid(NX, NY, px, py, [rank], ops, dist, domain=domain, smoother="jacobi", omega=0.8,
                                   cycle="V", pre=2, post=2)
     solver.set_problem(lambda b: sine_rhs_block(b, domain))
@@ -487,7 +492,7 @@ def bench_main(args, rank, local_rank, world):
             "metric": "MDoF/s per V-cycle", "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"2D Poisson {NX}x{NY} fp32, V(2,2) weighted-Jacobi omega=0.8, {px}x{py} block "
+            "config": {"workload": f"2D Poisson {NX}x{NY} fp32 (coarsest level fp64), V(2,2) weighted-Jacobi omega=0.8, {px}x{py} block "
                                    f"decomposition ({args.n}^2 per GPU), RCCL halo exchange, {solver.L} levels "
                                    f"({solver.Ld} distributed, rest replicated after all-gather)",
                        "grid": [NX, NY], "levels": solver.L, "cycle": "V(2,2)", "smoother": "jacobi",

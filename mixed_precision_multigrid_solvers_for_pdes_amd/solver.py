@@ -33,7 +33,7 @@ def _precision_config(grid, pm):
         # non-adaptive 'mixed' resolves to get_dtype(MIXED) = float64 on every level (precision.py:348-349)
         return (_lib.MG_PREC_MIXED_LEVELS if pm.adaptive else _lib.MG_PREC_DOUBLE), thr, mem, False
     if not pm.adaptive:
-        return (_lib.MG_PREC_SINGLE if pm.current_precision == PrecisionLevel.SINGLE else _lib.MG_PREC_DOUBLE), thr, mem, False
+        return (_lib.MG_PREC_SINGLE_MANAGED if pm.current_precision == PrecisionLevel.SINGLE else _lib.MG_PREC_DOUBLE), thr, mem, False
     return _lib.MG_PREC_ADAPTIVE, thr, mem, bool(getattr(pm, "reference_rule", True))
 
 
@@ -154,7 +154,7 @@ class MultigridSolver(BaseSolver):
                 if level != pm.current_precision:
                     pm.current_precision = level
                     pm.precision_history.append(level)
-        if pm is not None and eng.cfg.precision == _lib.MG_PREC_ADAPTIVE and r["precision_codes"] and r["precision_codes"][-1] == 0:
+        if pm is not None and eng.cfg.precision in (_lib.MG_PREC_ADAPTIVE, _lib.MG_PREC_SINGLE_MANAGED) and r["precision_codes"] and r["precision_codes"][-1] == 0:
             u = u.astype(np.float32)        # the reference returns the fp32 iterate while in SINGLE
         self.level_stats = eng.level_timings() if self.profile else self.level_stats
         self._last = dict(r, wall=wall)

@@ -18,17 +18,19 @@ import dist_helpers as H                                                        
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, "managed32"])
 @pytest.mark.parametrize("px,py,NX,NY,agg", [(2, 1, 513, 257, 65), (2, 2, 513, 513, 129), (4, 2, 1025, 513, 129), (1, 2, 257, 1025, 33)])
 @pytest.mark.parametrize("cyc,kind,omega", [("V", "jacobi", 0.8), ("W", "rbgs", 1.0)])
 def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cyc, kind, omega):
     import torch
+    managed = dtype == "managed32"
+    dtype = np.float32 if managed else dtype
     rng = np.random.default_rng(NX + NY)
     rhs = rng.standard_normal((NX, NY)).astype(dtype)
     u0 = rng.standard_normal((NX, NY)).astype(dtype)
     levels = mg.default_max_levels(NX, NY)
     ncyc = 2
-    prec = _lib.MG_PREC_SINGLE if dtype == np.float32 else _lib.MG_PREC_DOUBLE
+    prec = (_lib.MG_PREC_SINGLE_MANAGED if managed else _lib.MG_PREC_SINGLE) if dtype == np.float32 else _lib.MG_PREC_DOUBLE
     eng = mg.MultigridEngine(NX, NY, max_levels=levels, cycle=cyc, smoother=_lib.MG_JACOBI if kind == "jacobi" else _lib.MG_RBGS,
                              omega=omega, precision=prec)
     eng.set_rhs(rhs); eng.set_solution(u0)
@@ -38,7 +40,7 @@ def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cy
     u_ref = eng.get_solution(dtype)
     eng.close()
 
-    ops = D.HipOps(dtype, torch.device("cuda", 0))
+    ops = D.HipOps(dtype, torch.device("cuda", 0), managed_single=managed)
     s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle=cyc, smoother=kind,
                                omega=omega, agglomerate_at=agg)
     assert s.Ld >= 2
