@@ -510,6 +510,89 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
 }
 
 
+// --------------------------------------------------------------------------------------------
+// Lexicographic Gauss-Seidel, software-pipelined ACROSS sweeps, for tiny grids (one wave).
+//   Cell (i,j) of sweep k needs the sweep-k values of (i-1,j),(i,j-1) and the sweep-(k-1) values of
+//   (i+1,j),(i,j+1).  Give cell c on anti-diagonal d = i+j the time slot t = 2k + d: at time t every cell with
+//   (t - d) even is updated IN PLACE from its four neighbours' current values -- they are exactly the
+//   required sweep-k / sweep-(k-1) values, because neighbours sit on diagonals d-1 / d+1 and were updated
+//   at t-1.  One sweep then costs two time steps instead of nx+ny-5, with bit-identical arithmetic.
+//   The reference tests ||r|| after every complete sweep (solvers/base.py:271-283), so each cell also logs
+//   its sweep-k value into a ring of H snapshots; sweep k is complete at t = 2k + dmax, its residual norm is
+//   evaluated from snapshot k, and when it meets the tolerance (or k == maxit) snapshot k IS the result
+//   (the few speculative updates of later sweeps are dropped).  Returns the number of sweeps.
+// --------------------------------------------------------------------------------------------
+constexpr int kPipeCells = 81;     // up to 9 x 9
+constexpr int kPipeSlots = 9;      // >= (dmax - 2) / 2 + 2 for 9 x 9 (dmax = 14)
+
+template <typename T>
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <typename T>
+__device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* __restrict__ hist, int nx, int ny,
+                               T hx2, T hy2, T diag, T coeff, T omega, T one_m_omega, bool exact, double hxhy,
+                               double tol, int maxit, int lane) {
+  const int ncell = nx * ny, dmax = nx + ny - 4;
+  const int H = (dmax - 1) / 2 + 2;
+  const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
+  double ring = 0.0;
+  for (int c = lane; c < ncell; c += 64) {
+    const int i = c / ny, j = c - i * ny;
+    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) {
+      ring += (double)sf[c] * (double)sf[c];
+      for (int h = 0; h < H; ++h) hist[h * ncell + c] = su[c];
+    }
+  }
+  ring = wave_reduce_sum(ring);
+  ring = __shfl(ring, 0, 64);
+  wave_lds_fence<T>();
+  int sweeps = maxit;
+  for (int t = 4;; ++t) {
+    for (int c = lane; c < ncell; c += 64) {
+      const int i = c / ny, j = c - i * ny;
+      if (i < 1 || i > nx - 2 || j < 1 || j > ny - 2) continue;
+      const int td = t - (i + j);
+      if (td & 1) continue;
+      const int k = td >> 1;
+      if (k < 1 || k > maxit) continue;
+      const T sx = su[c + ny] + su[c - ny], sy = su[c + 1] + su[c - 1];
+      const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
+      const T num = sf[c] + nb;
+      const T un = exact ? num * rdiag : num / diag;
+      const T v = one_m_omega * su[c] + omega * un;
+      su[c] = v;
+      hist[(k % H) * ncell + c] = v;
+    }
+    wave_lds_fence<T>();
+    const int tc = t - dmax;
+    if (tc >= 2 && !(tc & 1)) {
+      const int kc = tc >> 1;
+      const T* snap = hist + (kc % H) * ncell;
+      double acc = 0.0;
+      for (int c = lane; c < ncell; c += 64) {
+        const int i = c / ny, j = c - i * ny;
+        if (i < 1 || i > nx - 2 || j < 1 || j > ny - 2) continue;
+        const T sx = snap[c + ny] + snap[c - ny], sy = snap[c + 1] + snap[c - 1];
+        const T rv = sf[c] - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap[c] * diag);
+        acc += (double)rv * (double)rv;
+      }
+      acc = wave_reduce_sum(acc);
+      acc = __shfl(acc, 0, 64);
+      if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
+        for (int c = lane; c < ncell; c += 64) su[c] = snap[c];
+        sweeps = kc;
+        break;
+      }
+    }
+  }
+  wave_lds_fence<T>();
+  return sweeps;
+}
+
 // Small-grid variant (nx*ny <= kCoarseLdsCells): ONE wave, u and rhs live in LDS for the whole solve, the
 // stop test is a wave64 shuffle reduction.  Same arithmetic and sweep order as coarse_lexgs_kernel; the L2
 // round trip per anti-diagonal (the whole cost of a 5x5 solve) is gone.
@@ -524,6 +607,7 @@ __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ 
   const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
   __shared__ T su[kCoarseLdsCells];
   __shared__ T sf[kCoarseLdsCells];
+  __shared__ T hist[kPipeCells * kPipeSlots];
   const int lane = threadIdx.x;
   for (int idx = lane; idx < nx * ny; idx += 64) {
     const int i = idx / ny, j = idx - i * ny;
@@ -531,6 +615,17 @@ __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ 
     sf[idx] = rhs[(size_t)i * ld + j];
   }
   __syncthreads();
+  if (nx * ny <= kPipeCells && (nx + ny - 5) / 2 + 2 <= kPipeSlots) {
+    const int sw = lexgs_pipelined<T>(su, sf, hist, nx, ny, hx2, hy2, diag, coeff, omega, one_m_omega, exact_recip != 0,
+                                      hxhy, tol, maxit, lane);
+    __syncthreads();
+    for (int idx = lane; idx < nx * ny; idx += 64) {
+      const int i = idx / ny, j = idx - i * ny;
+      if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1) u[(size_t)i * ld + j] = su[idx];
+    }
+    if (lane == 0 && sweeps_out) *sweeps_out = sw;
+    return;
+  }
   int it = 0;
   for (it = 1; it <= maxit; ++it) {
     for (int sdiag = 2; sdiag <= nx + ny - 4; ++sdiag) {
@@ -699,6 +794,12 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
           for (int c = lane; c < nx * ny; c += 64) su[c] = TCO(0);
           __builtin_amdgcn_wave_barrier();
         }
+        if (nx * ny <= kPipeCells && (nx + ny - 5) / 2 + 2 <= kPipeSlots) {
+          TCO* hist = Flast + nx * ny;       // kPipeSlots snapshots behind the last level's arrays
+          const int sw = lexgs_pipelined<TCO>(Ulast, Flast, hist, nx, ny, hx2, hy2, diag, cf, TCO(1), TCO(0), exact, L.hxhy,
+                                              a.tol, a.maxit, lane);
+          if (lane == 0 && sweeps_out) *sweeps_out = sw;
+        } else {
         int it = 0;
         for (it = 1; it <= a.maxit; ++it) {
           for (int sdiag = 2; sdiag <= nx + ny - 4; ++sdiag) {
@@ -728,6 +829,7 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
           if (sqrt(L.hxhy * acc) < a.tol) break;
         }
         if (lane == 0 && sweeps_out) *sweeps_out = (it > a.maxit) ? a.maxit : it;
+        }
       }
       __syncthreads();
     } else {   // kTailUp: u_l += P u_{l+1}, then the post sweeps

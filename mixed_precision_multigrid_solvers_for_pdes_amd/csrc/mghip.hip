@@ -545,7 +545,7 @@ size_t tail_pool_bytes(const mg_handle* h, int k, size_t esz, size_t esz_last) {
     b += (l == h->L() - 1) ? 2 * cells * esz_last : 3 * cells * esz;
     b = (b + 15) / 16 * 16;
   }
-  return b;
+  return b + (size_t)mg::kPipeCells * mg::kPipeSlots * esz_last;   // snapshot ring of the pipelined coarsest solve
 }
 
 void tail_schedule(const mg_handle* h, int k, int l, int zero_flag, std::vector<int>& ops) {
@@ -614,6 +614,7 @@ int launch_tail(mg_handle* h, bool zero_top) {
     off += (l == L - 1) ? 2 * cells * esize(dco) : 3 * cells * esize(dt);
     off = (off + 15) / 16 * 16;
   }
+  off += (size_t)mg::kPipeCells * mg::kPipeSlots * esize(dco);
   Level& top = h->lv[k];
   const dim3 grid(1), block(mg::kTailBlock);
   if (dt == MG_F64)
