@@ -551,6 +551,58 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
   ring = __shfl(ring, 0, 64);
   wave_lds_fence<T>();
   int sweeps = maxit;
+  if (ncell <= 64) {
+    // one cell per lane: everything that does not change with time lives in registers (a single wave issues
+    // one instruction every few cycles, so the loop body is kept to the loads, ~10 flops and two stores)
+    const int c = lane;
+    const int ci = c / ny, cj = c - ci * ny;
+    const bool interior = c < ncell && ci >= 1 && ci <= nx - 2 && cj >= 1 && cj <= ny - 2;
+    const T fv = interior ? sf[c] : T(0);
+    T uv = interior ? su[c] : T(0);
+    int tnext = 2 + ci + cj;            // time of this cell's next update: 2k + d with k = 1
+    int knext = 1;
+    T* hslot = hist + c;                // snapshot slot of sweep knext (slot index knext % H, advanced incrementally)
+    int hs = 1 % H;
+    hslot += hs * ncell;
+    const T* snap = hist + (1 % H) * ncell;   // snapshot of the next sweep to complete
+    int cs = 1 % H, kc = 1;
+    int tdone = 2 + dmax;               // time at which sweep kc is complete
+    for (int t = 4;; ++t) {
+      if (interior && t == tnext && knext <= maxit) {
+        const T sx = su[c + ny] + su[c - ny], sy = su[c + 1] + su[c - 1];
+        const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
+        const T num = fv + nb;
+        const T un = exact ? num * rdiag : num / diag;
+        uv = one_m_omega * uv + omega * un;
+        su[c] = uv;
+        *hslot = uv;
+        tnext += 2;
+        ++knext;
+        if (++hs == H) { hs = 0; hslot = hist + c; } else hslot += ncell;
+      }
+      wave_lds_fence<T>();
+      if (t == tdone) {
+        double acc = 0.0;
+        if (interior) {
+          const T sx = snap[c + ny] + snap[c - ny], sy = snap[c + 1] + snap[c - 1];
+          const T rv = fv - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap[c] * diag);
+          acc = (double)rv * (double)rv;
+        }
+        acc = wave_reduce_sum(acc);
+        acc = __shfl(acc, 0, 64);
+        if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
+          if (c < ncell) su[c] = snap[c];
+          sweeps = kc;
+          break;
+        }
+        ++kc;
+        tdone += 2;
+        if (++cs == H) { cs = 0; snap = hist; } else snap += ncell;
+      }
+    }
+    wave_lds_fence<T>();
+    return sweeps;
+  }
   for (int t = 4;; ++t) {
     for (int c = lane; c < ncell; c += 64) {
       const int i = c / ny, j = c - i * ny;
