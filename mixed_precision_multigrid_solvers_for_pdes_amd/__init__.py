@@ -14,6 +14,8 @@ from .smoothers import (BaseSolver, ConvergenceHistory, EnhancedJacobiSolver, Ga
 from .solver import GPUMultigridSolver, MultigridCycle, MultigridSolver
 from .engine import MultigridEngine
 from .facade import MixedPrecisionMultigrid, PoissonProblem, default_max_levels
+from . import applications
+from .applications import MultigridPreconditioner, PoissonSolver2D
 
 __all__ = [
     "Grid", "BaseOperator", "LaplacianOperator", "RestrictionOperator", "ProlongationOperator",
@@ -21,5 +23,6 @@ __all__ = [
     "JacobiSmoother", "WeightedJacobiSmoother", "EnhancedJacobiSolver", "GaussSeidelSmoother",
     "MultigridSolver", "GPUMultigridSolver", "MultigridCycle", "MultigridEngine",
     "MixedPrecisionMultigrid", "PoissonProblem", "default_max_levels",
+    "PoissonSolver2D", "MultigridPreconditioner", "applications",
 ]
 __version__ = "0.1.0"
