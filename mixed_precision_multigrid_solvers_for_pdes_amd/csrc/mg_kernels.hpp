@@ -33,6 +33,10 @@ constexpr int kNumXcd = 8;
 // TAG values of the tile kernels: same code, distinct symbols, so that a kernel trace (rocprofv3 --stats)
 // reports the finest-level launches separately from the many small coarse-level ones.
 constexpr int kCoarseTag = 0, kFineTag = 1;
+// smoother selectors of the fused legs / coarse tail
+constexpr int kSmJacobi = 0, kSmRbgs = 1;
+// halo cells one full sweep consumes: 1 for Jacobi, 2 for red-black GS (one per colour pass)
+__host__ __device__ constexpr int sweep_halo(int sm) { return sm == kSmRbgs ? 2 : 1; }
 
 template <typename T> struct VecW { static constexpr int N = 16 / sizeof(T); };
 
@@ -736,6 +740,8 @@ struct TailLevel {
 };
 struct TailArgs {
   int nlev, nops, pre, post, ld_top, maxit;
+  int smoother;                // kSmJacobi / kSmRbgs
+  int colour_offset;
   double omega, coeff, tol;
   TailLevel lv[kTailMaxLevels];
 };
@@ -750,6 +756,21 @@ __device__ __forceinline__ void tail_sweep(const T* __restrict__ src, T* __restr
     const T nb = ihx2 * (src[idx + ny] + src[idx - ny]) + ihy2 * (src[idx + 1] + src[idx - 1]);
     const T un = L.use_div ? (f[idx] + nb) / D : (f[idx] + nb) * invD;
     dst[idx] = one_m_omega * src[idx] + omega * un;
+  }
+}
+
+// one colour pass of red-black GS, in place (solvers/smoothers.py:183-205)
+template <typename T>
+__device__ __forceinline__ void tail_rb_pass(T* __restrict__ u, const T* __restrict__ f, const TailLevel& L, T omega,
+                                             T one_m_omega, int colour, int poff) {
+  const T ihx2 = (T)L.ihx2, ihy2 = (T)L.ihy2, invD = (T)L.invD, D = (T)L.diag;
+  const int ny = L.ny, ni = L.nx - 2, nj = ny - 2;
+  for (int c = threadIdx.x; c < ni * nj; c += kTailBlock) {
+    const int i = 1 + c / nj, j = 1 + c % nj, idx = i * ny + j;
+    if (((i + j + poff) & 1) != colour) continue;
+    const T nb = ihx2 * (u[idx + ny] + u[idx - ny]) + ihy2 * (u[idx + 1] + u[idx - 1]);
+    const T un = L.use_div ? (f[idx] + nb) / D : (f[idx] + nb) * invD;
+    u[idx] = one_m_omega * u[idx] + omega * un;
   }
 }
 
@@ -798,9 +819,16 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
         __syncthreads();
       }
       for (int s = 0; s < a.pre; ++s) {
-        tail_sweep<T>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega);
-        cur ^= (1u << l);
-        __syncthreads();
+        if (a.smoother == kSmRbgs) {
+          for (int colour = 0; colour < 2; ++colour) {
+            tail_rb_pass<T>(Ubuf(l, (cur >> l) & 1), Fbuf(l), L, omega, one_m_omega, colour, a.colour_offset);
+            __syncthreads();
+          }
+        } else {
+          tail_sweep<T>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega);
+          cur ^= (1u << l);
+          __syncthreads();
+        }
       }
       // residual of interior cells into the non-current buffer (its ring is never touched)
       const T* u = Ubuf(l, (cur >> l) & 1);
@@ -908,9 +936,16 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
       }
       __syncthreads();
       for (int s = 0; s < a.post; ++s) {
-        tail_sweep<T>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega);
-        cur ^= (1u << l);
-        __syncthreads();
+        if (a.smoother == kSmRbgs) {
+          for (int colour = 0; colour < 2; ++colour) {
+            tail_rb_pass<T>(Ubuf(l, (cur >> l) & 1), Fbuf(l), L, omega, one_m_omega, colour, a.colour_offset);
+            __syncthreads();
+          }
+        } else {
+          tail_sweep<T>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega);
+          cur ^= (1u << l);
+          __syncthreads();
+        }
       }
     }
   }
@@ -964,11 +999,12 @@ struct FusedArgs {
   int nx, ny, ld, nyv;          // fine level
   int tiles_j, ntiles;
   int nsweep;
+  int colour_offset;            // parity of the global index of local cell (0,0) (red-black colouring)
   int use_div;                  // 1: divide by the diagonal (1/D not exact)
   int nxc, nyc, ldc;            // coarse level (restriction target / prolongation source)
 };
 
-template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG>
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM>
 __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
     const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
     const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
@@ -1022,6 +1058,39 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   // reads RPT + 2 row vectors (not 3 RPT) plus the two lateral scalars per row.
   T* src = bufA;
   T* dst = bufB;
+  if (SM == kSmRbgs) {
+    // Red-black Gauss-Seidel IN PLACE in bufA: colour 0 = (i+j) even first (solvers/smoothers.py:183-205).  A colour
+    // pass reads only the other colour (plus the cell itself) and rewrites other-colour cells with the values it
+    // read, so concurrent vector stores never change what a neighbour reads.  Each pass costs one halo cell.
+    for (int s = 0; s < 2 * a.nsweep; ++s) {
+      const int colour = s & 1;
+#pragma unroll
+      for (int k = 0; k < S::RPT; ++k) {
+        const int r = r_base + k, gi = ri0 + r;
+        if (!worker || r >= S::RI) continue;
+        if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+          const Pack<T> up = *reinterpret_cast<const Pack<T>*>(src + (r - 1) * S::RJ + lc);
+          const Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc);
+          const Pack<T> dn = *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc);
+          const T left = src[r * S::RJ + lc - 1];
+          const T right = src[r * S::RJ + lc + N];
+          Pack<T> o = mid;
+#pragma unroll
+          for (int e = 0; e < N; ++e) {
+            const T w = (e == 0) ? left : mid.v[e - 1];
+            const T ea = (e == N - 1) ? right : mid.v[e + 1];
+            const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
+            const T un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
+            const T res = one_m_omega * mid.v[e] + omega * un;
+            const int gj = gj0 + e;
+            if (gj >= 1 && gj < a.ny - 1 && (((gi + gj + a.colour_offset) & 1) == colour)) o.v[e] = res;
+          }
+          *reinterpret_cast<Pack<T>*>(src + r * S::RJ + lc) = o;
+        }
+      }
+      __syncthreads();
+    }
+  } else
   for (int s = 0; s < a.nsweep; ++s) {
     if (worker && r_base < S::RI) {
       Pack<T> up = (r_base >= 1) ? *reinterpret_cast<const Pack<T>*>(src + (r_base - 1) * S::RJ + lc) : zero_pack<T>();

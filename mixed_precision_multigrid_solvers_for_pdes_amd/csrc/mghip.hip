@@ -245,7 +245,7 @@ void d_coarse(int dt, void* u, const void* rhs, int nx, int ny, int ld, double h
 
 // ------------------------------------------------------------------ fused legs ----------------
 template <typename T, int HALO>
-mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int nxc, int nyc, int ldc) {
+mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int nxc, int nyc, int ldc, int poff) {
   using S = mg::FusedShape<T, HALO>;
   mg::FusedArgs a;
   a.nx = nx; a.ny = ny; a.ld = ld;
@@ -253,59 +253,105 @@ mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int n
   const int tiles_i = (nx - 2 + mg::kTI - 1) / mg::kTI;
   a.tiles_j = (ny - 1 + S::TJ - 1) / S::TJ;
   a.ntiles = tiles_i * a.tiles_j;
-  a.nsweep = nsweep; a.use_div = use_div ? 1 : 0;
+  a.nsweep = nsweep; a.use_div = use_div ? 1 : 0; a.colour_offset = poff & 1;
   a.nxc = nxc; a.nyc = nyc; a.ldc = ldc;
   return a;
 }
 
+struct LegGeom {      // what every fused launch needs
+  int nx, ny, ld, nxc, nyc, ldc;
+  double hx, hy, omega, coeff;
+  int nsweep, poff;
+  bool fine;
+};
+
 // down leg: nsweep sweeps + residual + full-weighting restriction (interior coarse cells).  TX = coarse rhs dtype.
-template <typename T, typename TX>
-void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, int nx, int ny, int ld, int nxc, int nyc, int ldc,
-                 double hx, double hy, double omega, double coeff, int nsweep, bool zero_init, bool fine, hipStream_t st) {
-  const Coef c = coefs(hx, hy);
-  const mg::FusedArgs a = fused_args<T, 4>(nx, ny, ld, nsweep, !c.pow2, nxc, nyc, ldc);
+template <typename T, typename TX, int SM>
+void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
+  constexpr int HALO = 2 * mg::sweep_halo(SM) + 2;
+  const Coef c = coefs(g.hx, g.hy);
+  const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
   void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T);
-  if (zero_init) k = fine ? mg::fused_jacobi_kernel<T, 4, false, mg::kPostRestrict, true, TX, T, 1>
-                          : mg::fused_jacobi_kernel<T, 4, false, mg::kPostRestrict, true, TX, T, 0>;
-  else k = fine ? mg::fused_jacobi_kernel<T, 4, false, mg::kPostRestrict, false, TX, T, 1>
-                : mg::fused_jacobi_kernel<T, 4, false, mg::kPostRestrict, false, TX, T, 0>;
+  if (zero_init) k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM>
+                            : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 0, SM>;
+  else k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 1, SM>
+                  : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 0, SM>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr,
-                     (TX*)rhs_c, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), (T)coeff);
+                     (TX*)rhs_c, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
 }
 
 // up leg: u += P e, nsweep sweeps, optional sum of r^2 over interior cells.  TX = coarse e dtype, TC = interpolation dtype.
 // returns the number of partials (0 without norm)
-template <typename T, typename TX, typename TC>
-int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double* partials, int nx, int ny, int ld, int nxc,
-              int nyc, int ldc, double hx, double hy, double omega, double coeff, int nsweep, bool norm, bool fine,
+template <typename T, typename TX, typename TC, int SM>
+int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm,
               hipStream_t st) {
-  const Coef c = coefs(hx, hy);
+  const Coef c = coefs(g.hx, g.hy);
   if (norm) {
-    const mg::FusedArgs a = fused_args<T, 3>(nx, ny, ld, nsweep, !c.pow2, nxc, nyc, ldc);
-    auto k = fine ? mg::fused_jacobi_kernel<T, 3, true, mg::kPostNorm, false, TX, TC, 1>
-                  : mg::fused_jacobi_kernel<T, 3, true, mg::kPostNorm, false, TX, TC, 0>;
+    constexpr int HALO = 2 * mg::sweep_halo(SM) + 1;
+    const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+    auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM>
+                    : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 0, SM>;
     hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
-                       (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), (T)coeff);
+                       (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
     return a.ntiles;
   }
-  const mg::FusedArgs a = fused_args<T, 2>(nx, ny, ld, nsweep, !c.pow2, nxc, nyc, ldc);
-  auto k = fine ? mg::fused_jacobi_kernel<T, 2, true, mg::kPostNone, false, TX, TC, 1>
-                : mg::fused_jacobi_kernel<T, 2, true, mg::kPostNone, false, TX, TC, 0>;
+  constexpr int HALO = 2 * mg::sweep_halo(SM);
+  const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+  auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM>
+                  : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 0, SM>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
-                     (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), (T)coeff);
+                     (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
   return 0;
 }
 
 // plain multi-sweep smoothing (nsweep <= 2 per launch)
-template <typename T>
-void launch_sweeps(const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy, double omega,
-                   int nsweep, bool fine, hipStream_t st) {
-  const Coef c = coefs(hx, hy);
-  const mg::FusedArgs a = fused_args<T, 2>(nx, ny, ld, nsweep, !c.pow2, 0, 0, 0);
-  auto k = fine ? mg::fused_jacobi_kernel<T, 2, false, mg::kPostNone, false, T, T, 1>
-                : mg::fused_jacobi_kernel<T, 2, false, mg::kPostNone, false, T, T, 0>;
+template <typename T, int SM>
+void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
+  constexpr int HALO = 2 * mg::sweep_halo(SM);
+  const Coef c = coefs(g.hx, g.hy);
+  const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, 0, 0, 0, g.poff);
+  auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM>
+                  : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 0, SM>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr,
-                     (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)omega, (T)(1.0 - omega), (T)0);
+                     (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0);
+}
+
+template <int SM>
+void d_down_sm(int dt, int dx, const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
+  if (dt == MG_F32 && dx == MG_F32) launch_down<float, float, SM>(u, rhs, out, rhs_c, g, zero_init, st);
+  else if (dt == MG_F64 && dx == MG_F64) launch_down<double, double, SM>(u, rhs, out, rhs_c, g, zero_init, st);
+  else if (dt == MG_F64 && dx == MG_F32) launch_down<double, float, SM>(u, rhs, out, rhs_c, g, zero_init, st);
+  else launch_down<float, double, SM>(u, rhs, out, rhs_c, g, zero_init, st);
+}
+void d_down(int sm, int dt, int dx, const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init,
+            hipStream_t st) {
+  if (sm == MG_RBGS) d_down_sm<mg::kSmRbgs>(dt, dx, u, rhs, out, rhs_c, g, zero_init, st);
+  else d_down_sm<mg::kSmJacobi>(dt, dx, u, rhs, out, rhs_c, g, zero_init, st);
+}
+// dt: fine dtype, dx: coarse e dtype, dcomp: interpolation dtype.  Returns #partials, or -1 for an unsupported combination.
+template <int SM>
+int d_up_sm(int dt, int dx, int dcomp, const void* u, const void* rhs, void* out, const void* e_c, double* partials,
+            const LegGeom& g, bool norm, hipStream_t st) {
+  if (dcomp == MG_F32) {
+    if (dt == MG_F32 && dx == MG_F32) return launch_up<float, float, float, SM>(u, rhs, out, e_c, partials, g, norm, st);
+    return -1;
+  }
+  if (dt == MG_F64 && dx == MG_F64) return launch_up<double, double, double, SM>(u, rhs, out, e_c, partials, g, norm, st);
+  if (dt == MG_F64 && dx == MG_F32) return launch_up<double, float, double, SM>(u, rhs, out, e_c, partials, g, norm, st);
+  if (dt == MG_F32 && dx == MG_F64) return launch_up<float, double, double, SM>(u, rhs, out, e_c, partials, g, norm, st);
+  return launch_up<float, float, double, SM>(u, rhs, out, e_c, partials, g, norm, st);
+}
+int d_up(int sm, int dt, int dx, int dcomp, const void* u, const void* rhs, void* out, const void* e_c, double* partials,
+         const LegGeom& g, bool norm, hipStream_t st) {
+  return sm == MG_RBGS ? d_up_sm<mg::kSmRbgs>(dt, dx, dcomp, u, rhs, out, e_c, partials, g, norm, st)
+                       : d_up_sm<mg::kSmJacobi>(dt, dx, dcomp, u, rhs, out, e_c, partials, g, norm, st);
+}
+void d_sweeps(int sm, int dt, const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
+  if (sm == MG_RBGS) {
+    if (dt == MG_F32) launch_sweeps<float, mg::kSmRbgs>(u, rhs, out, g, st); else launch_sweeps<double, mg::kSmRbgs>(u, rhs, out, g, st);
+  } else {
+    if (dt == MG_F32) launch_sweeps<float, mg::kSmJacobi>(u, rhs, out, g, st); else launch_sweeps<double, mg::kSmJacobi>(u, rhs, out, g, st);
+  }
 }
 
 template <typename TI, typename TO>
@@ -314,31 +360,6 @@ void launch_inject_ring(const void* fine, void* coarse, int ldf, int nxc, int ny
                      (const TI*)fine, (TO*)coarse, ldf, nxc, nyc, ldc);
 }
 
-void d_down(int dt, int dx, const void* u, const void* rhs, void* out, void* rhs_c, int nx, int ny, int ld, int nxc, int nyc,
-            int ldc, double hx, double hy, double omega, double coeff, int nsweep, bool zero_init, bool fine, hipStream_t st) {
-  if (dt == MG_F32 && dx == MG_F32) launch_down<float, float>(u, rhs, out, rhs_c, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, zero_init, fine, st);
-  else if (dt == MG_F64 && dx == MG_F64) launch_down<double, double>(u, rhs, out, rhs_c, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, zero_init, fine, st);
-  else if (dt == MG_F64 && dx == MG_F32) launch_down<double, float>(u, rhs, out, rhs_c, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, zero_init, fine, st);
-  else launch_down<float, double>(u, rhs, out, rhs_c, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, zero_init, fine, st);
-}
-// dt: fine dtype, dx: coarse e dtype, dcomp: interpolation dtype.  Returns #partials, or -1 for an unsupported combination.
-int d_up(int dt, int dx, int dcomp, const void* u, const void* rhs, void* out, const void* e_c, double* partials, int nx,
-         int ny, int ld, int nxc, int nyc, int ldc, double hx, double hy, double omega, double coeff, int nsweep, bool norm,
-         bool fine, hipStream_t st) {
-  if (dcomp == MG_F32) {
-    if (dt == MG_F32 && dx == MG_F32) return launch_up<float, float, float>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
-    return -1;
-  }
-  if (dt == MG_F64 && dx == MG_F64) return launch_up<double, double, double>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
-  if (dt == MG_F64 && dx == MG_F32) return launch_up<double, float, double>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
-  if (dt == MG_F32 && dx == MG_F64) return launch_up<float, double, double>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
-  return launch_up<float, float, double>(u, rhs, out, e_c, partials, nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, norm, fine, st);
-}
-void d_sweeps(int dt, const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy, double omega,
-              int nsweep, bool fine, hipStream_t st) {
-  if (dt == MG_F32) launch_sweeps<float>(u, rhs, out, nx, ny, ld, hx, hy, omega, nsweep, fine, st);
-  else launch_sweeps<double>(u, rhs, out, nx, ny, ld, hx, hy, omega, nsweep, fine, st);
-}
 void d_inject_ring(int di, int dout, const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
   if (di == MG_F32 && dout == MG_F32) launch_inject_ring<float, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
   else if (di == MG_F64 && dout == MG_F64) launch_inject_ring<double, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
@@ -430,7 +451,7 @@ struct mg_handle {
     }
   }
   int level_dtype(int l) const { return level_dtype_in(l, phase); }
-  bool fused() const { return cfg.fused != 0 && cfg.smoother == MG_JACOBI; }
+  bool fused() const { return cfg.fused != 0 && (cfg.smoother == MG_JACOBI || cfg.smoother == MG_RBGS); }
   bool needs(int l, int dt) const {
     if (cfg.precision == MG_PREC_ADAPTIVE) return (l == L() - 1) ? dt == grid_dtype : true;
     return level_dtype(l) == dt;
@@ -602,6 +623,7 @@ int launch_tail(mg_handle* h, bool zero_top) {
   a.nlev = L - k; a.nops = h->tail_nops; a.pre = h->cfg.pre; a.post = h->cfg.post;
   a.ld_top = h->lv[k].ld[dt]; a.maxit = h->cfg.coarse_maxit;
   a.omega = h->cfg.omega; a.coeff = h->cfg.coeff; a.tol = h->cfg.coarse_tol;
+  a.smoother = (h->cfg.smoother == MG_RBGS) ? mg::kSmRbgs : mg::kSmJacobi; a.colour_offset = h->cfg.colour_offset & 1;
   size_t off = 0;
   for (int l = k; l < L; ++l) {
     const Level& v = h->lv[l];
@@ -644,18 +666,20 @@ int cycle_fused(mg_handle* h, int l, bool zero_u) {
   Level& c = h->lv[l + 1];
   const int dc = h->level_dtype(l + 1);
   const bool fine = (l == 0);
+  const int sm = h->cfg.smoother;
+  LegGeom g{f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, 0, h->cfg.colour_offset, fine};
   {
     StageTimer tm(h, &f, 0);
     int extra = std::max(0, h->cfg.pre - 2);
     if (extra > 0 && zero_u) { (void)hipMemsetAsync(f.u[dt], 0, bytes, h->stream); zero_u = false; }
     while (extra > 0) {
-      const int n = std::min(2, extra);
-      d_sweeps(dt, f.u[dt], f.rhs[dt], f.t[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.omega, n, fine, h->stream);
+      g.nsweep = std::min(2, extra);
+      d_sweeps(sm, dt, f.u[dt], f.rhs[dt], f.t[dt], g, h->stream);
       std::swap(f.u[dt], f.t[dt]);
-      extra -= n;
+      extra -= g.nsweep;
     }
-    d_down(dt, dc, f.u[dt], f.rhs[dt], f.t[dt], c.rhs[dc], f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy,
-           h->cfg.omega, h->cfg.coeff, std::min(2, h->cfg.pre), zero_u, fine, h->stream);
+    g.nsweep = std::min(2, h->cfg.pre);
+    d_down(sm, dt, dc, f.u[dt], f.rhs[dt], f.t[dt], c.rhs[dc], g, zero_u, h->stream);
     std::swap(f.u[dt], f.t[dt]);
   }
   int reps = 1;
@@ -668,18 +692,17 @@ int cycle_fused(mg_handle* h, int l, bool zero_u) {
   {
     StageTimer tm(h, &f, 2);
     const bool want_norm = fine && h->cfg.post <= 2;
-    const int n = d_up(dt, dc, h->grid_dtype, f.u[dt], f.rhs[dt], f.t[dt], c.u[dc], h->partials, f.nx, f.ny, f.ld[dt],
-                       c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, std::min(2, h->cfg.post), want_norm,
-                       fine, h->stream);
+    g.nsweep = std::min(2, h->cfg.post);
+    const int n = d_up(sm, dt, dc, h->grid_dtype, f.u[dt], f.rhs[dt], f.t[dt], c.u[dc], h->partials, g, want_norm, h->stream);
     if (n < 0) return MG_ERR_INVALID_VALUE;
     std::swap(f.u[dt], f.t[dt]);
     if (fine) h->norm_partials = want_norm ? n : 0;
     int extra = std::max(0, h->cfg.post - 2);
     while (extra > 0) {
-      const int m = std::min(2, extra);
-      d_sweeps(dt, f.u[dt], f.rhs[dt], f.t[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.omega, m, fine, h->stream);
+      g.nsweep = std::min(2, extra);
+      d_sweeps(sm, dt, f.u[dt], f.rhs[dt], f.t[dt], g, h->stream);
       std::swap(f.u[dt], f.t[dt]);
-      extra -= m;
+      extra -= g.nsweep;
     }
   }
   return MG_OK;
@@ -933,7 +956,7 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
       if ((rc = alloc_zero(&h->err, &v.rhs[dt], bytes, h->stream)) != MG_OK) return bail(rc);
       if (l < h->L() - 1) {
         if ((rc = alloc_zero(&h->err, &v.r[dt], bytes, h->stream)) != MG_OK) return bail(rc);
-        if (cfg->smoother == MG_JACOBI && (rc = alloc_zero(&h->err, &v.t[dt], bytes, h->stream)) != MG_OK) return bail(rc);
+        if ((cfg->smoother == MG_JACOBI || h->fused()) && (rc = alloc_zero(&h->err, &v.t[dt], bytes, h->stream)) != MG_OK) return bail(rc);
       }
     }
   }
@@ -1175,7 +1198,8 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
   Level& v = h->lv[level];
   const int dt = dtype;
   if (op != 6 && (!v.u[dt] || !v.rhs[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: level has no arrays of that dtype");
-  if ((op == 0 || op >= 7) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
+  if (op == 0 && h->cfg.smoother != MG_JACOBI) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
+  if ((op == 0 || op >= 7) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no ping-pong buffer on this level");
   if ((op == 2 || op == 4 || op == 5 || op == 7 || op == 8) && (level >= h->L() - 1 || !v.r[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no coarser level");
   h->norm_partials = 0;
   hipEvent_t e0, e1;
@@ -1196,15 +1220,16 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
                   if (d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], v.u[dt], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE; } break;
         case 6: { const int rc = run_cycle(h); if (rc != MG_OK) return rc; } break;
         case 7: { Level& c = h->lv[level + 1]; const int dc = c.rhs[dt] ? dt : 1 - dt;          // down leg
-                  d_down(dt, dc, v.u[dt], v.rhs[dt], v.t[dt], c.rhs[dc], v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy,
-                         h->cfg.omega, h->cfg.coeff, 2, false, level == 0, h->stream);
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0};
+                  d_down(h->cfg.smoother, dt, dc, v.u[dt], v.rhs[dt], v.t[dt], c.rhs[dc], g, false, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         case 8: { Level& c = h->lv[level + 1]; const int dc = c.u[dt] ? dt : 1 - dt;            // up leg (+ norm on level 0)
-                  if (d_up(dt, dc, h->grid_dtype, v.u[dt], v.rhs[dt], v.t[dt], c.u[dc], h->partials, v.nx, v.ny, v.ld[dt], c.nx, c.ny,
-                           c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, level == 0, level == 0, h->stream) < 0) return MG_ERR_INVALID_VALUE;
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0};
+                  if (d_up(h->cfg.smoother, dt, dc, h->grid_dtype, v.u[dt], v.rhs[dt], v.t[dt], c.u[dc], h->partials, g, level == 0, h->stream) < 0) return MG_ERR_INVALID_VALUE;
                   std::swap(v.u[dt], v.t[dt]); } break;
-        case 9: d_sweeps(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, 2, level == 0, h->stream);
-                std::swap(v.u[dt], v.t[dt]); break;
+        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0};
+                  d_sweeps(h->cfg.smoother, dt, v.u[dt], v.rhs[dt], v.t[dt], g, h->stream);
+                  std::swap(v.u[dt], v.t[dt]); } break;
         default: return MG_ERR_INVALID_VALUE;
       }
     }

@@ -158,10 +158,11 @@ def test_device_resident_stepping_equals_solve():
     eng.close()
 
 
+@pytest.mark.parametrize("sm,omega", [("jacobi", 0.8), ("rbgs", 1.0), ("rbgs", 1.15)])
 @pytest.mark.parametrize("prec", ["double", "single", "mixed", "adaptive"])
 @pytest.mark.parametrize("n,cyc,pre,post", [(257, "V", 2, 2), (129, "W", 2, 2), (513, "V", 1, 1), (129, "V", 3, 0), (65, "F", 0, 4),
                                             ((97, 193), "V", 2, 1), (1025, "V", 2, 2)])
-def test_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post):
+def test_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post, sm, omega):
     """The fused down/up legs (temporal blocking in LDS) must reproduce the operator-by-operator cycle bit for bit,
     including the norm they accumulate on the way (to reduction round-off)."""
     from mixed_precision_multigrid_solvers_for_pdes_amd import _lib
@@ -174,8 +175,8 @@ def test_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post):
     res = []
     for fused, tail in ((True, True), (True, False), (False, False)):
         eng = mg.MultigridEngine(nx, ny, max_levels=mg.default_max_levels(nx, ny), cycle=cyc, pre=pre, post=post,
-                                 smoother=_lib.MG_JACOBI, omega=0.8, precision=code, switch_threshold=1e-3,
-                                 coarse_maxit=60, fused=fused, tail=tail)
+                                 smoother=_lib.MG_JACOBI if sm == "jacobi" else _lib.MG_RBGS, omega=omega, precision=code,
+                                 switch_threshold=1e-3, coarse_maxit=60, fused=fused, tail=tail)
         u, r = eng.solve(rhs, u0, tol=1e-30, max_iterations=6)
         eng.close()
         res.append((u, r))
