@@ -17,9 +17,12 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 ops = sys.argv[3:] or ["jacobi", "sweeps2", "down_leg", "up_leg", "residual", "residual_norm", "restrict", "prolong"]
 x = np.linspace(0, 1, n)
 rhs = 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
-for smoother, names in ((_lib.MG_JACOBI, [o for o in ops if o != "rbgs"]), (_lib.MG_RBGS, [o for o in ops if o == "rbgs"])):
+RB = [o for o in ops if o.startswith("rb:")]
+for smoother, names in ((_lib.MG_JACOBI, [o for o in ops if o != "rbgs" and not o.startswith("rb:")]),
+                        (_lib.MG_RBGS, [o for o in ops if o == "rbgs"] + [o[3:] for o in RB])):
     if not names:
         continue
+    print("--- smoother:", "jacobi" if smoother == _lib.MG_JACOBI else "red-black GS")
     eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), smoother=smoother,
                              omega=0.8 if smoother == _lib.MG_JACOBI else 1.0, precision=_lib.MG_PREC_ADAPTIVE)
     eng.set_rhs(rhs)
