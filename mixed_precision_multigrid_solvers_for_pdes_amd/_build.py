@@ -30,16 +30,31 @@ def is_stale():
 
 
 def build_library(force=False, verbose=False):
-    """Compile csrc/*.hip -> lib/libmghip.so.  Returns the library path."""
+    """Compile csrc/*.hip -> lib/libmghip.so.  Returns the library path.
+
+    Several ranks may import the package at once (torch.distributed.run): the build is serialised with a file
+    lock and the library is written to a temporary name and renamed into place, so nobody maps a half-written file."""
     if not force and not is_stale():
         return LIBPATH
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc_path()] + FLAGS + ["-o", LIBPATH] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():          # another process built it while we waited
+                return LIBPATH
+            tmp = f"{LIBPATH}.{os.getpid()}.tmp"
+            cmd = [hipcc_path()] + FLAGS + ["-o", tmp] + SOURCES
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+            os.replace(tmp, LIBPATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIBPATH
 
 
