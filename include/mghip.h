@@ -79,6 +79,8 @@ typedef struct mg_config {
                                 two launches per level, identical arithmetic); 0: one launch per operator */
   int32_t tail;              /* with fused = 1 -- 1: all levels of <= ~65^2 cells incl. the coarsest solve run in ONE
                                 workgroup with their fields in LDS (one launch per visit); 0: per-level launches */
+  int32_t speculate;         /* with fused = 1 -- 1: mg_iterate / mg_solve queue the down leg of cycle k+1 while ||r_k||
+                                travels to the host (dropped if that norm ends the solve); 0: strictly one cycle at a time */
 } mg_config;
 
 typedef struct mg_stats {

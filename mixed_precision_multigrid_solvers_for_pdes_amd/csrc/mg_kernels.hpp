@@ -981,13 +981,17 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
 // them; coarse-level rhs boundary cells (injection of r = f) are written once when the rhs is set.
 // ============================================================================================
 constexpr int kFusedBlock = 512;
+#ifndef MG_FUSED_TI
+#define MG_FUSED_TI 32
+#endif
+constexpr int kFusedTI = MG_FUSED_TI;      // tile rows of the fused legs (even: coarse rows sit on every other tile row)
 constexpr int kPostNone = 0, kPostRestrict = 1, kPostNorm = 2;
 
 template <typename T, int HALO> struct FusedShape {
   static constexpr int N = VecW<T>::N;
   static constexpr int TJ = kTileRowBytes / (int)sizeof(T);
   static constexpr int HV = (HALO + N - 1) / N;               // halo vectors per side
-  static constexpr int RI = kTI + 2 * HALO;                   // region rows
+  static constexpr int RI = kFusedTI + 2 * HALO;                   // region rows
   static constexpr int RJ = TJ + 2 * HV * N;                  // region cols
   static constexpr int VPR = RJ / N;                          // vectors per region row
   static constexpr int RG = kFusedBlock / VPR;                // row groups
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
 
   const int L = xcd_remap(blockIdx.x, a.ntiles);
   const int ti = L / a.tiles_j, tj = L - ti * a.tiles_j;
-  const int i0 = 1 + ti * kTI, j0 = tj * S::TJ;
+  const int i0 = 1 + ti * kFusedTI, j0 = tj * S::TJ;
   const int ri0 = i0 - HALO, rj0 = j0 - S::HV * N;           // global coords of region cell (0,0)
   const int cv = threadIdx.x % S::VPR, rg = threadIdx.x / S::VPR;
   const bool worker = rg < S::RG;
@@ -1130,7 +1134,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   for (int k = 0; k < S::RPT; ++k) {
     const int r = r_base + k, gi = ri0 + r;
     if (!worker || r >= S::RI) continue;
-    if (r >= HALO && r < HALO + kTI && cv >= S::HV && cv < S::HV + S::TJ / N && gi < a.nx && gj0 < a.nyv)
+    if (r >= HALO && r < HALO + kFusedTI && cv >= S::HV && cv < S::HV + S::TJ / N && gi < a.nx && gj0 < a.nyv)
       stg(out + (size_t)gi * a.ld + gj0, *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc));
   }
 
@@ -1147,7 +1151,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
       if (r >= S::RI) break;
       const Pack<T> dn = (r + 1 < S::RI) ? *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc) : zero_pack<T>();
       Pack<T> o = f[k];
-      const bool in_tile = r >= HALO && r < HALO + kTI && cv >= S::HV && cv < S::HV + S::TJ / N;
+      const bool in_tile = r >= HALO && r < HALO + kFusedTI && cv >= S::HV && cv < S::HV + S::TJ / N;
       const bool wanted = (POST == kPostRestrict) || in_tile;      // the norm only needs r on the tile itself
       if (wanted && r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
         const T left = src[r * S::RJ + lc - 1];
@@ -1178,7 +1182,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
 
   // ---- full-weighting restriction of the interior coarse cells that sit on this tile ---------------
   __syncthreads();
-  constexpr int CI = kTI / 2, CJ = S::TJ / 2;          // coarse cells per tile
+  constexpr int CI = kFusedTI / 2, CJ = S::TJ / 2;          // coarse cells per tile
   for (int c = threadIdx.x; c < CI * CJ; c += kFusedBlock) {
     const int ci = c / CJ, cj = c - ci * CJ;
     const int fi = i0 + 1 + 2 * ci, fj = j0 + 2 * cj;  // i0 is odd: even fine rows are i0+1, i0+3, ...

@@ -250,7 +250,7 @@ mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int n
   mg::FusedArgs a;
   a.nx = nx; a.ny = ny; a.ld = ld;
   a.nyv = std::min(ld, (ny + S::N - 1) / S::N * S::N);
-  const int tiles_i = (nx - 2 + mg::kTI - 1) / mg::kTI;
+  const int tiles_i = (nx - 2 + mg::kFusedTI - 1) / mg::kFusedTI;
   a.tiles_j = (ny - 1 + S::TJ - 1) / S::TJ;
   a.ntiles = tiles_i * a.tiles_j;
   a.nsweep = nsweep; a.use_div = use_div ? 1 : 0; a.colour_offset = poff & 1;
@@ -653,7 +653,11 @@ int launch_tail(mg_handle* h, bool zero_top) {
 
 // Fused V/W/F-cycle: two launches per level (down leg, up leg) instead of nine.  Same arithmetic per cell.
 // zero_u: the iterate of this level is the zero correction and need not be read (first visit of a coarse level).
-int cycle_fused(mg_handle* h, int l, bool zero_u) {
+constexpr int kPartFull = 0, kPartFront = 1, kPartBack = 2;
+
+// `part` (level 0 only) splits the cycle for speculative launching: the FRONT part (down leg + the whole
+// sub-cycle below) never writes the buffer that holds the current fine iterate, only the BACK part (up leg) does.
+int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   const int L = h->L();
   Level& f = h->lv[l];
   const int dt = h->level_dtype(l);
@@ -668,7 +672,7 @@ int cycle_fused(mg_handle* h, int l, bool zero_u) {
   const bool fine = (l == 0);
   const int sm = h->cfg.smoother;
   LegGeom g{f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, 0, h->cfg.colour_offset, fine};
-  {
+  if (part != kPartBack) {
     StageTimer tm(h, &f, 0);
     int extra = std::max(0, h->cfg.pre - 2);
     if (extra > 0 && zero_u) { (void)hipMemsetAsync(f.u[dt], 0, bytes, h->stream); zero_u = false; }
@@ -685,11 +689,11 @@ int cycle_fused(mg_handle* h, int l, bool zero_u) {
   int reps = 1;
   if (h->cfg.cycle == MG_CYCLE_W) reps = 2;
   else if (h->cfg.cycle == MG_CYCLE_F) reps = std::max(1, 1 << std::max(0, L - l - 2));
-  for (int k = 0; k < reps; ++k) {
+  for (int k = 0; k < reps && part != kPartBack; ++k) {
     const int rc = cycle_fused(h, l + 1, k == 0);
     if (rc != MG_OK) return rc;
   }
-  {
+  if (part != kPartFront) {
     StageTimer tm(h, &f, 2);
     const bool want_norm = fine && h->cfg.post <= 2;
     g.nsweep = std::min(2, h->cfg.post);
@@ -717,6 +721,27 @@ int run_cycle(mg_handle* h) {
 // Reduce `n` partial sums and bring the scalar to the host.  Fast path: the kernel posts it to the mapped
 // mailbox and the host spins on the sequence number (a few microseconds after the kernel retires); if nothing
 // arrives within 2 s, or there is no mailbox, fall back to copy + stream synchronisation.
+// launch half of reduce_to_host (mailbox only): returns the sequence number to wait for
+unsigned long long reduce_post(mg_handle* h, int n) {
+  const unsigned long long seq = ++h->mbox_seq;
+  launch_reduce(h->partials, n, h->d_scalar, h->stream, h->mbox_dev, seq);
+  return seq;
+}
+
+int reduce_wait(mg_handle* h, unsigned long long seq, double* value) {
+  volatile unsigned long long* flag = &h->mbox->seq;
+  const double t0 = now_s();
+  long spins = 0;
+  while (*flag != seq) {
+    if ((++spins & 0x3fff) == 0 && now_s() - t0 > 2.0) break;
+  }
+  if (*flag != seq) HIPC(&h->err, hipStreamSynchronize(h->stream));     // slow or faulted device
+  if (*flag != seq) return fail(&h->err, MG_ERR_HIP, "norm mailbox was never written");
+  std::atomic_thread_fence(std::memory_order_acquire);
+  *value = *(volatile double*)&h->mbox->value;
+  return MG_OK;
+}
+
 int reduce_to_host(mg_handle* h, int n, double* value) {
   if (h->mbox_dev) {
     const unsigned long long seq = ++h->mbox_seq;
@@ -1125,21 +1150,67 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
   if (rc != MG_OK) return rc;
   st->initial_residual = rn;
   int it = 0, conv = 0, switches = 0;
+  // Speculative launching: while the norm of cycle `it` travels to the host, the FRONT part of cycle it+1 (level-0
+  // down leg and everything below it) is already queued -- it never touches the buffer holding the iterate of
+  // cycle `it`.  If that norm ends the solve or changes the working precision, the front part is simply dropped
+  // (one pointer swap is undone); results are identical to the one-cycle-at-a-time loop.
+  const bool can_spec = h->cfg.speculate != 0 && h->fused() && h->L() > 1 && h->mbox_dev && h->cfg.pre <= 2 &&
+                        h->cfg.post <= 2 && !h->cfg.profile && h->ring_sumsq[0] >= 0 && h->ring_sumsq[1] >= 0;
+  bool spec = false;       // the front part of the coming cycle is already queued
+  auto undo_front = [&]() {
+    Level& v0 = h->lv[0];
+    const int d0 = h->level_dtype(0);
+    std::swap(v0.u[d0], v0.t[d0]);
+    spec = false;
+  };
   for (it = 1; it <= max_iter; ++it) {
     const int before = h->phase;
-    if ((rc = adapt(h, rn)) != MG_OK) return rc;               // solvers/multigrid.py:224-227
+    if (spec && h->cfg.precision == MG_PREC_ADAPTIVE) {
+      // would the policy switch?  evaluate it on a copy of the state first
+      const int to_before = h->phase;
+      const bool prom = h->promoted;
+      if ((rc = adapt(h, rn)) != MG_OK) return rc;
+      if (h->phase != to_before) {
+        // adapt() has converted the iterate out of lv[0].u -- which, after the speculative swap, is the WRONG buffer:
+        // redo it properly from the untouched iterate
+        h->phase = to_before; h->promoted = prom;
+        undo_front();
+        if ((rc = adapt(h, rn)) != MG_OK) return rc;
+      }
+    } else {
+      if ((rc = adapt(h, rn)) != MG_OK) return rc;               // solvers/multigrid.py:224-227
+    }
     if (h->phase != before) {
       ++switches;
       if (h->cfg.adaptive_reference_rule == 0) h->adapt_hist.clear();
     }
-    if ((rc = run_cycle(h)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
-    if ((rc = fine_norm(h, &rn)) != MG_OK) return rc;         // multigrid.py:233
+    if (can_spec) {
+      h->norm_partials = 0;
+      if (!spec && (rc = cycle_fused(h, 0, false, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+      spec = false;
+      if ((rc = cycle_fused(h, 0, false, kPartBack)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+      const unsigned long long seq = reduce_post(h, h->norm_partials);
+      if (it < max_iter) {
+        if ((rc = cycle_fused(h, 0, false, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+        spec = true;
+      }
+      HIPC(&h->err, hipGetLastError());
+      double ss = 0;
+      if ((rc = reduce_wait(h, seq, &ss)) != MG_OK) return rc;
+      const int d0 = h->level_dtype(0);
+      rn = std::sqrt(h->lv[0].hx * h->lv[0].hy * (ss + h->ring_sumsq[d0]));
+      if (spec) h->norm_partials = 0;        // `partials` still describes cycle `it`, but lv[0].u is ahead of it
+    } else {
+      if ((rc = run_cycle(h)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+      if ((rc = fine_norm(h, &rn)) != MG_OK) return rc;         // multigrid.py:233
+    }
     h->adapt_hist.push_back(rn);
     if (it <= hist_cap) hist[it - 1] = rn;
     if (prec_hist && it <= hist_cap)
       prec_hist[it - 1] = (h->cfg.precision == MG_PREC_MIXED_LEVELS) ? 2 : h->level_dtype(0);
     if (rn < tol) { conv = 1; break; }                         // solvers/base.py:134 (absolute)
   }
+  if (spec) undo_front();                                      // a queued front part is dropped: lv[0].u is the iterate again
   if (it > max_iter) it = max_iter;
   HIPC(&h->err, hipMemcpyAsync(h->h_int, h->d_int, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPC(&h->err, hipStreamSynchronize(h->stream));

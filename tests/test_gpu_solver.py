@@ -176,7 +176,7 @@ def test_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post, sm, o
     for fused, tail in ((True, True), (True, False), (False, False)):
         eng = mg.MultigridEngine(nx, ny, max_levels=mg.default_max_levels(nx, ny), cycle=cyc, pre=pre, post=post,
                                  smoother=_lib.MG_JACOBI if sm == "jacobi" else _lib.MG_RBGS, omega=omega, precision=code,
-                                 switch_threshold=1e-3, coarse_maxit=60, fused=fused, tail=tail)
+                                 switch_threshold=1e-3, coarse_maxit=60, fused=fused, tail=tail, speculate=tail)
         u, r = eng.solve(rhs, u0, tol=1e-30, max_iterations=6)
         eng.close()
         res.append((u, r))
@@ -186,3 +186,26 @@ def test_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post, sm, o
     np.testing.assert_allclose(rf["residual_history"], ru["residual_history"], rtol=1e-11)
     np.testing.assert_allclose(rt["residual_history"], ru["residual_history"], rtol=1e-11)
     assert rf["precision_codes"] == ru["precision_codes"] == rt["precision_codes"]
+
+
+@pytest.mark.parametrize("prec,thr", [("double", 1e-6), ("adaptive", 1e-3), ("adaptive", 1e-6), ("mixed", 1e-6)])
+def test_speculative_launching_changes_nothing(prec, thr):
+    """mg_iterate queues the front part of cycle k+1 while ||r_k|| is in flight; stopping on tolerance and precision
+    switches must leave exactly the iterate, history and switch points of the one-cycle-at-a-time loop."""
+    from mixed_precision_multigrid_solvers_for_pdes_amd import _lib
+    code = {"double": _lib.MG_PREC_DOUBLE, "mixed": _lib.MG_PREC_MIXED_LEVELS, "adaptive": _lib.MG_PREC_ADAPTIVE}[prec]
+    n = 257
+    rhs = O.sine_rhs(n, n)
+    out = []
+    for spec in (True, False):
+        eng = mg.MultigridEngine(n, n, max_levels=7, smoother=_lib.MG_JACOBI, omega=0.8, precision=code, switch_threshold=thr,
+                                 speculate=spec)
+        u, r = eng.solve(rhs, tol=1e-9, max_iterations=40)
+        u2, r2 = eng.solve(rhs, tol=1e-30, max_iterations=7)        # ends on max_iter with a front part never queued
+        eng.close()
+        out.append((u, r, u2, r2))
+    (ua, ra, ua2, ra2), (ub, rb, ub2, rb2) = out
+    assert ra["converged"] and ra["iterations"] == rb["iterations"] and ra["precision_codes"] == rb["precision_codes"]
+    np.testing.assert_array_equal(ua, ub); np.testing.assert_array_equal(ua2, ub2)
+    np.testing.assert_array_equal(ra["residual_history"], rb["residual_history"])
+    np.testing.assert_array_equal(ra2["residual_history"], rb2["residual_history"])
