@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=4097, help="grid points per direction per GPU")
+    ap.add_argument("--grid-n", dest="n", type=int, default=4097, help="grid points per direction per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
