@@ -209,3 +209,23 @@ def test_speculative_launching_changes_nothing(prec, thr):
     np.testing.assert_array_equal(ua, ub); np.testing.assert_array_equal(ua2, ub2)
     np.testing.assert_array_equal(ra["residual_history"], rb["residual_history"])
     np.testing.assert_array_equal(ra2["residual_history"], rb2["residual_history"])
+
+
+def test_bench_size_4097_two_cycles_equal_oracle():
+    """At the bench size itself: two V(2,2) Jacobi cycles of the fused fp64 engine at 4097^2 against the NumPy oracle
+    (about 1 s per oracle cycle) -- bit-identical iterate, norms to reduction round-off."""
+    from mixed_precision_multigrid_solvers_for_pdes_amd import _lib
+    n = 4097
+    rhs = O.sine_rhs(n, n)
+    ref = O.MGOracle(n, n, max_levels=11, cycle="V", smoother="jacobi", omega=0.8, jacobi_form="vectorized")
+    ref.rhs[0] = rhs.copy()
+    u_ref = np.zeros_like(rhs)
+    h_ref = []
+    for _ in range(2):
+        u_ref = ref.cycle_once(u_ref, 0)
+        h_ref.append(ref.residual_norm(u_ref, rhs, 0))
+    eng = mg.MultigridEngine(n, n, max_levels=11, smoother=_lib.MG_JACOBI, omega=0.8)
+    u, r = eng.solve(rhs, tol=0.0, max_iterations=2)
+    eng.close()
+    np.testing.assert_array_equal(u, u_ref)
+    np.testing.assert_allclose(r["residual_history"], h_ref, rtol=1e-11)
