@@ -122,3 +122,27 @@ def test_large_1025_history(golden_large):
     u, info = mg.solve(rhs, tol=1e-10, max_iterations=3)
     np.testing.assert_allclose(info["residual_history"], ref[:3], rtol=1e-9)
     assert len(mg.shapes) == 9 and mg.shapes[-1] == (5, 5)
+
+
+@pytest.mark.parametrize("n,levels,cyc,kind,omega", [(129, 6, "V", "jacobi", 0.8), (65, 5, "W", "rbgs", 1.0), ((65, 33), 4, "V", "rbgs", 1.15),
+                                                     (33, 4, "F", "jacobi", 2.0 / 3.0)])
+def test_c_oracle_equals_numpy_oracle(n, levels, cyc, kind, omega):
+    """oracle/mg_oracle.c (the multi-threaded CPU baseline of bench.py) reproduces the pinned NumPy oracle bit for bit."""
+    from oracle.c_oracle import COracle
+    nx, ny = (n, n) if isinstance(n, int) else n
+    rng = np.random.default_rng(nx)
+    rhs = O.sine_rhs(nx, ny) + 0.01 * rng.standard_normal((nx, ny))
+    rhs[0, :] = rhs[-1, :] = rhs[:, 0] = rhs[:, -1] = 0.0          # converge the coarsest solve (stop test at round-off)
+    u0 = rng.standard_normal((nx, ny))
+    ref = O.MGOracle(nx, ny, max_levels=levels, cycle=cyc, smoother=kind, omega=omega, jacobi_form="vectorized")
+    ref.rhs[0] = rhs.copy()
+    u = u0.copy()
+    co = COracle(nx, ny, max_levels=levels, cycle=cyc, smoother=kind, omega=omega)
+    co.set_problem(rhs, u0)
+    for _ in range(3):
+        u = ref.cycle_once(u, 0)
+        co.cycle()
+    got = co.solution()
+    assert np.max(np.abs(got - u)) <= 1e-13 * np.max(np.abs(u))      # the coarsest stop test may differ by one sweep
+    np.testing.assert_allclose(co.residual_norm(), ref.residual_norm(u, rhs, 0), rtol=1e-9)
+    co.close()
