@@ -124,6 +124,13 @@ int mg_solve(mg_handle* h, const void* rhs, const void* u0, void* u_out, int hos
 int mg_iterate(mg_handle* h, double tol, int max_iter, double* hist, int hist_cap, int* n_iter, int* converged,
                int32_t* prec_hist, mg_stats* stats);
 
+/* Variable-coefficient operator A = coeff * div(a grad .) (BASELINE config 5; NOT in the reference, SURVEY F12: our
+ * design, parity unpinned -- a == 1 reproduces the constant-coefficient path bit for bit on dyadic grids).
+ * `a` holds vertex values on the fine grid (host array, (nx, ny)); face values are arithmetic means; coarse
+ * operators are re-discretised with `a` injected.  NULL switches back to the constant-coefficient operator.
+ * Cycles of a variable-coefficient handle run one launch per operator (the fused legs are constant-coefficient). */
+int mg_set_coefficient(mg_handle* h, const void* a_host_or_null, int host_dtype);
+
 /* Device-resident stepping (benchmarks, preconditioner-style callers: fixed cycle counts, no transfer). */
 int mg_set_rhs(mg_handle* h, const void* rhs, int host_dtype);
 int mg_set_solution(mg_handle* h, const void* u0_or_null, int host_dtype);
@@ -161,6 +168,10 @@ int mg_op_norm(int dtype, int nx, int ny, double hx, double hy, const void* fiel
 int mg_op_jacobi(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* u, const void* rhs, void* out);
 /* replaces: solvers/smoothers.py:117-151,175-207, gpu/cuda_kernels.py:348-390 (red_black_gauss_seidel) */
 int mg_op_rbgs(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* u, const void* rhs, void* out);
+/* variable-coefficient forms of residual / Jacobi / red-black GS (no reference counterpart, see mg_set_coefficient) */
+int mg_op_residual_var(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* a, const void* u, const void* f, void* r);
+int mg_op_jacobi_var(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* a, const void* u, const void* rhs, void* out);
+int mg_op_rbgs_var(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* a, const void* u, const void* rhs, void* out);
 /* replaces: operators/transfer.py:53-81,100-124, gpu/cuda_kernels.py:738-764 (TransferKernels.restriction) */
 int mg_op_restrict_fw(int in_dtype, int out_dtype, int nx, int ny, const void* fine, void* coarse);
 /* replaces: operators/transfer.py:189-215,234-267, gpu/cuda_kernels.py:766-792 (TransferKernels.prolongation) */

@@ -7,7 +7,7 @@ MultigridSolver, GPUMultigridSolver) plus the README facade (MixedPrecisionMulti
 PoissonProblem).  Device side: csrc/ -> lib/libmghip.so, reached through the C ABI in
 include/mghip.h.  There is no CPU fallback for the device path."""
 from .grid import Grid
-from .operators import BaseOperator, LaplacianOperator, ProlongationOperator, RestrictionOperator
+from .operators import BaseOperator, DiffusionOperator, LaplacianOperator, ProlongationOperator, RestrictionOperator
 from .precision import PrecisionLevel, PrecisionManager
 from .smoothers import (BaseSolver, ConvergenceHistory, EnhancedJacobiSolver, GaussSeidelSmoother,
                         IterativeSolver, JacobiSmoother, WeightedJacobiSmoother)
@@ -18,7 +18,7 @@ from . import applications
 from .applications import MultigridPreconditioner, PoissonSolver2D
 
 __all__ = [
-    "Grid", "BaseOperator", "LaplacianOperator", "RestrictionOperator", "ProlongationOperator",
+    "Grid", "BaseOperator", "LaplacianOperator", "DiffusionOperator", "RestrictionOperator", "ProlongationOperator",
     "PrecisionLevel", "PrecisionManager", "BaseSolver", "ConvergenceHistory", "IterativeSolver",
     "JacobiSmoother", "WeightedJacobiSmoother", "EnhancedJacobiSolver", "GaussSeidelSmoother",
     "MultigridSolver", "GPUMultigridSolver", "MultigridCycle", "MultigridEngine",

@@ -162,8 +162,15 @@ void launch_convert(const void* in, void* out, int nx, int ny, int ldi, int ldo,
 
 template <typename T>
 void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff, double omega,
-                   double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false) {
+                   double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false, const void* a = nullptr) {
   const Coef c = coefs(hx, hy);
+  if (a) {          // variable coefficient: the general one-workgroup kernel
+    if (zero_init) (void)hipMemsetAsync(u, 0, (size_t)nx * ld * sizeof(T), st);
+    hipLaunchKernelGGL(mg::coarse_lexgs_kernel<T>, dim3(1), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
+                       (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol, maxit,
+                       sweeps_dev, (const T*)a);
+    return;
+  }
   if (nx * ny <= mg::kCoarseLdsCells) {
     hipLaunchKernelGGL(mg::coarse_lexgs_small_kernel<T>, dim3(1), dim3(64), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
                        (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol, maxit,
@@ -173,7 +180,7 @@ void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, 
   if (zero_init) (void)hipMemsetAsync(u, 0, (size_t)nx * ld * sizeof(T), st);
   hipLaunchKernelGGL(mg::coarse_lexgs_kernel<T>, dim3(1), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
                      (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol,
-                     maxit, sweeps_dev);
+                     maxit, sweeps_dev, (const T*)nullptr);
 }
 
 // ------------------------------------------------------------------ dtype dispatch --------------
@@ -237,11 +244,44 @@ void d_convert(int di, int dout, const void* in, void* out, int nx, int ny, int 
   else launch_convert<float, double>(in, out, nx, ny, ldi, ldo, st);
 }
 void d_coarse(int dt, void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff,
-              double omega, double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false) {
-  if (dt == MG_F32) launch_coarse<float>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init);
-  else launch_coarse<double>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init);
+              double omega, double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false,
+              const void* a = nullptr) {
+  if (dt == MG_F32) launch_coarse<float>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init, a);
+  else launch_coarse<double>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init, a);
 }
 
+
+
+// ------------------------------------------------------------------ variable coefficient ------
+template <typename T, int MODE>
+int launch_var(const void* u, const void* a, const void* f, void* out, double* partials, int nx, int ny, int ld, double hx,
+               double hy, double omega, double coeff, int colour, int poff, hipStream_t st) {
+  if (nx < 3 || ny < 3) return 0;
+  const Coef c = coefs(hx, hy);
+  const bool interior_only = (MODE == mg::kVarJacobi || MODE == mg::kVarRbgs);
+  const mg::TileGeom g = make_geom<T>(nx, ny, ld, interior_only);
+  hipLaunchKernelGGL((mg::varcoef_kernel<T, MODE>), dim3(g.ntiles), dim3(mg::kBlock), 0, st, (const T*)u, (const T*)a,
+                     (const T*)f, (T*)out, partials, g, (T)c.ihx2, (T)c.ihy2, (T)omega, (T)(1.0 - omega), (T)coeff, colour,
+                     poff & 1);
+  return g.ntiles;
+}
+template <int MODE>
+int d_var(int dt, const void* u, const void* a, const void* f, void* out, double* partials, int nx, int ny, int ld, double hx,
+          double hy, double omega, double coeff, int colour, int poff, hipStream_t st) {
+  return dt == MG_F32 ? launch_var<float, MODE>(u, a, f, out, partials, nx, ny, ld, hx, hy, omega, coeff, colour, poff, st)
+                      : launch_var<double, MODE>(u, a, f, out, partials, nx, ny, ld, hx, hy, omega, coeff, colour, poff, st);
+}
+template <typename TI, typename TO>
+void launch_inject(const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
+  hipLaunchKernelGGL((mg::inject_kernel<TI, TO>), dim3(grid_for((long long)nxc * nyc)), dim3(mg::kBlock), 0, st,
+                     (const TI*)fine, (TO*)coarse, ldf, nxc, nyc, ldc);
+}
+void d_inject(int di, int dout, const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
+  if (di == MG_F32 && dout == MG_F32) launch_inject<float, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
+  else if (di == MG_F64 && dout == MG_F64) launch_inject<double, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
+  else if (di == MG_F64 && dout == MG_F32) launch_inject<double, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
+  else launch_inject<float, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
+}
 
 // ------------------------------------------------------------------ fused legs ----------------
 template <typename T, int HALO>
@@ -406,6 +446,7 @@ struct Level {
   void* t[2] = {nullptr, nullptr};     // Jacobi ping-pong partner (same boundary ring as u)
   void* rhs[2] = {nullptr, nullptr};
   void* r[2] = {nullptr, nullptr};     // residual
+  void* a[2] = {nullptr, nullptr};     // diffusion coefficient (variable-coefficient operator), else null
   double timings[3] = {0, 0, 0};       // smooth / restrict / prolong seconds (cfg.profile)
 };
 
@@ -429,6 +470,7 @@ struct mg_handle {
   int phase = MG_F64;           // working precision of the adaptive policy
   bool promoted = false;        // one-way rule: fp32 -> fp64 happened
   bool have_rhs = false;
+  bool varcoef = false;          // A = coeff * div(a grad .) with the per-level fields lv[l].a
   double ring_sumsq[2] = {0, 0};   // sum of f^2 over the boundary ring of the fine rhs, per dtype (r = f there)
   int norm_partials = 0;           // > 0: `partials` holds sum r^2 over interior cells of the CURRENT fine iterate
   int tail_start = -1;             // first level of the single-workgroup LDS tail (-1: none)
@@ -451,7 +493,7 @@ struct mg_handle {
     }
   }
   int level_dtype(int l) const { return level_dtype_in(l, phase); }
-  bool fused() const { return cfg.fused != 0 && (cfg.smoother == MG_JACOBI || cfg.smoother == MG_RBGS); }
+  bool fused() const { return cfg.fused != 0 && !varcoef && (cfg.smoother == MG_JACOBI || cfg.smoother == MG_RBGS); }
   bool needs(int l, int dt) const {
     if (cfg.precision == MG_PREC_ADAPTIVE) return (l == L() - 1) ? dt == grid_dtype : true;
     return level_dtype(l) == dt;
@@ -475,6 +517,7 @@ void release(mg_handle* h) {
       if (l.t[d]) (void)hipFree(l.t[d]);
       if (l.rhs[d]) (void)hipFree(l.rhs[d]);
       if (l.r[d]) (void)hipFree(l.r[d]);
+      if (l.a[d]) (void)hipFree(l.a[d]);
     }
   if (h->d_tail_ops) (void)hipFree(h->d_tail_ops);
   if (h->partials) (void)hipFree(h->partials);
@@ -503,7 +546,15 @@ void smooth(mg_handle* h, int l, int nu) {
   const int dt = h->level_dtype(l);
   StageTimer tm(h, &v, 0);
   for (int s = 0; s < nu; ++s) {
-    if (h->cfg.smoother == MG_JACOBI) {
+    if (h->varcoef && h->cfg.smoother == MG_JACOBI) {
+      d_var<mg::kVarJacobi>(dt, v.u[dt], v.a[dt], v.rhs[dt], v.t[dt], nullptr, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega,
+                            h->cfg.coeff, 0, 0, h->stream);
+      std::swap(v.u[dt], v.t[dt]);
+    } else if (h->varcoef && h->cfg.smoother == MG_RBGS) {
+      for (int colour = 0; colour < 2; ++colour)
+        d_var<mg::kVarRbgs>(dt, v.u[dt], v.a[dt], v.rhs[dt], v.u[dt], nullptr, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega,
+                            h->cfg.coeff, colour, h->cfg.colour_offset, h->stream);
+    } else if (h->cfg.smoother == MG_JACOBI) {
       d_jacobi(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, l == 0);
       std::swap(v.u[dt], v.t[dt]);
     } else if (h->cfg.smoother == MG_RBGS) {
@@ -512,7 +563,7 @@ void smooth(mg_handle* h, int l, int nu) {
                       h->cfg.colour_offset, h->stream, l == 0);
     } else {   // MG_LEXGS: exactly `nu` sweeps (tol < 0 never triggers the early exit)
       d_coarse(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, h->cfg.omega, -1.0, nu - s,
-               nullptr, h->stream);
+               nullptr, h->stream, false, h->varcoef ? v.a[dt] : nullptr);
       break;
     }
   }
@@ -523,7 +574,7 @@ void coarse_solve(mg_handle* h, int l, bool zero_init = false) {
   const int dt = h->level_dtype(l);
   // solvers/multigrid.py:119-124: the default coarse solver is GaussSeidelSmoother(omega = 1)
   d_coarse(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, 1.0, h->cfg.coarse_tol,
-           h->cfg.coarse_maxit, h->d_int, h->stream, zero_init);
+           h->cfg.coarse_maxit, h->d_int, h->stream, zero_init, h->varcoef ? v.a[dt] : nullptr);
 }
 
 int cycle(mg_handle* h, int l) {
@@ -535,7 +586,11 @@ int cycle(mg_handle* h, int l) {
   if (h->cfg.pre > 0) smooth(h, l, h->cfg.pre);
   {
     StageTimer tm(h, &f, 1);
-    d_residual(dt, f.u[dt], f.rhs[dt], f.r[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.coeff, h->stream, l == 0);
+    if (h->varcoef)
+      d_var<mg::kVarResidual>(dt, f.u[dt], f.a[dt], f.rhs[dt], f.r[dt], nullptr, f.nx, f.ny, f.ld[dt], f.hx, f.hy, 1.0,
+                              h->cfg.coeff, 0, 0, h->stream);
+    else
+      d_residual(dt, f.u[dt], f.rhs[dt], f.r[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.coeff, h->stream, l == 0);
     d_restrict(dt, dc, f.r[dt], c.rhs[dc], f.nx, f.ny, f.ld[dt], c.ld[dc], h->stream);
   }
   (void)hipMemsetAsync(c.u[dc], 0, (size_t)c.nx * c.ld[dc] * esize(dc), h->stream);
@@ -779,8 +834,10 @@ int fine_norm(mg_handle* h, double* out) {
     *out = std::sqrt(v.hx * v.hy * (ss + h->ring_sumsq[dt]));
     return MG_OK;
   }
-  const int n = d_residual_norm(dt, v.u[dt], v.rhs[dt], h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff,
-                                h->stream, true);
+  const int n = h->varcoef
+      ? d_var<mg::kVarResidualNorm>(dt, v.u[dt], v.a[dt], v.rhs[dt], nullptr, h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy,
+                                    1.0, h->cfg.coeff, 0, 0, h->stream)
+      : d_residual_norm(dt, v.u[dt], v.rhs[dt], h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, h->stream, true);
   double ss = 0;
   const int rc = reduce_to_host(h, n, &ss);
   if (rc != MG_OK) return rc;
@@ -1092,6 +1149,37 @@ int mg_set_rhs(mg_handle* h, const void* rhs, int host_dtype) {
   if (!h || !rhs || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_rhs: bad argument");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
   return set_rhs_impl(h, rhs, host_dtype);
+}
+
+
+int mg_set_coefficient(mg_handle* h, const void* a_host, int host_dtype) {
+  if (!h || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_coefficient: bad argument");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  h->norm_partials = 0;
+  if (!a_host) { h->varcoef = false; return MG_OK; }       // back to the constant-coefficient operator
+  // the coefficient lives in every precision a level may compute in; coarse levels: injection (re-discretisation)
+  for (int l = 0; l < h->L(); ++l) {
+    Level& v = h->lv[l];
+    for (int dt = 0; dt < 2; ++dt) {
+      if (!v.u[dt]) continue;
+      if (!v.a[dt]) { const int rc = alloc_zero(&h->err, &v.a[dt], (size_t)v.nx * v.ld[dt] * esize(dt), h->stream); if (rc != MG_OK) return rc; }
+      if (l == 0) {
+        const int rc = upload(&h->err, v.a[dt], dt, v.ld[dt], a_host, host_dtype, v.nx, v.ny, h->staging, h->stream);
+        if (rc != MG_OK) return rc;
+      }
+    }
+    if (l > 0) {
+      Level& f = h->lv[l - 1];
+      for (int dt = 0; dt < 2; ++dt) {
+        if (!v.a[dt]) continue;
+        const int df = f.a[dt] ? dt : 1 - dt;          // inject from the same precision when the finer level has it
+        d_inject(df, dt, f.a[df], v.a[dt], f.ld[df], v.nx, v.ny, v.ld[dt], h->stream);
+      }
+    }
+  }
+  HIPC(&h->err, hipStreamSynchronize(h->stream));
+  h->varcoef = true;
+  return MG_OK;
 }
 
 int mg_set_solution(mg_handle* h, const void* u0, int host_dtype) {
@@ -1488,6 +1576,42 @@ int mg_op_rbgs(int dtype, int nx, int ny, double hx, double hy, double omega, in
   RC(up(da, dtype, u, nx, ny)); RC(up(df, dtype, rhs, nx, ny));
   for (int k = 0; k < nu; ++k)
     for (int c = 0; c < 2; ++c) d_rbgs_colour(dtype, da, df, nx, ny, pitch_elems(dtype, ny), hx, hy, omega, c, 0, nullptr);
+  return down(out, dtype, da, nx, ny);
+}
+
+
+int mg_op_residual_var(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* a, const void* u, const void* f, void* r) {
+  CHECK_DEV(valid_dtype(dtype) && a && u && f && r && nx >= 3 && ny >= 3, "mg_op_residual_var: bad argument");
+  RC(need_device());
+  Scratch s; void *da, *du, *df, *dr;
+  RC(s.get(&da, dtype, nx, ny)); RC(s.get(&du, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny)); RC(s.get(&dr, dtype, nx, ny));
+  RC(up(da, dtype, a, nx, ny)); RC(up(du, dtype, u, nx, ny)); RC(up(df, dtype, f, nx, ny));
+  d_var<mg::kVarResidual>(dtype, du, da, df, dr, nullptr, nx, ny, pitch_elems(dtype, ny), hx, hy, 1.0, coeff, 0, 0, nullptr);
+  return down(r, dtype, dr, nx, ny);
+}
+
+int mg_op_jacobi_var(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* a, const void* u, const void* rhs, void* out) {
+  CHECK_DEV(valid_dtype(dtype) && a && u && rhs && out && nu >= 0 && nx >= 3 && ny >= 3, "mg_op_jacobi_var: bad argument");
+  RC(need_device());
+  Scratch s; void *dc, *da, *db, *df;
+  RC(s.get(&dc, dtype, nx, ny)); RC(s.get(&da, dtype, nx, ny)); RC(s.get(&db, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny));
+  RC(up(dc, dtype, a, nx, ny)); RC(up(da, dtype, u, nx, ny)); RC(up(db, dtype, u, nx, ny)); RC(up(df, dtype, rhs, nx, ny));
+  for (int k = 0; k < nu; ++k) {
+    d_var<mg::kVarJacobi>(dtype, da, dc, df, db, nullptr, nx, ny, pitch_elems(dtype, ny), hx, hy, omega, -1.0, 0, 0, nullptr);
+    std::swap(da, db);
+  }
+  return down(out, dtype, da, nx, ny);
+}
+
+int mg_op_rbgs_var(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* a, const void* u, const void* rhs, void* out) {
+  CHECK_DEV(valid_dtype(dtype) && a && u && rhs && out && nu >= 0 && nx >= 3 && ny >= 3, "mg_op_rbgs_var: bad argument");
+  RC(need_device());
+  Scratch s; void *dc, *da, *df;
+  RC(s.get(&dc, dtype, nx, ny)); RC(s.get(&da, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny));
+  RC(up(dc, dtype, a, nx, ny)); RC(up(da, dtype, u, nx, ny)); RC(up(df, dtype, rhs, nx, ny));
+  for (int k = 0; k < nu; ++k)
+    for (int c = 0; c < 2; ++c)
+      d_var<mg::kVarRbgs>(dtype, da, dc, df, da, nullptr, nx, ny, pitch_elems(dtype, ny), hx, hy, omega, -1.0, c, 0, nullptr);
   return down(out, dtype, da, nx, ny);
 }
 

@@ -99,6 +99,17 @@ class MultigridEngine:
                 "precision_codes": [prec[i] for i in range(n)], "initial_residual": stats.initial_residual,
                 "solve_seconds": stats.solve_seconds, "precision_switches": stats.precision_switches}
 
+    def set_coefficient(self, a):
+        """Variable-coefficient operator A = coeff * div(a grad .): vertex values of a on the fine grid (None: back
+        to the constant-coefficient operator)."""
+        if a is None:
+            self._check(self._lib.mg_set_coefficient(self._h, None, _lib.MG_F64))
+            return
+        a = _lib.as_c(a)
+        if a.shape != (self.nx, self.ny):
+            raise ValueError(f"coefficient shape {a.shape} doesn't match grid shape {(self.nx, self.ny)}")
+        self._check(self._lib.mg_set_coefficient(self._h, _lib.ptr(a), _lib.dtype_code(a.dtype)))
+
     # ---- device-resident stepping ---------------------------------------------------------
     def set_rhs(self, rhs):
         rhs = _lib.as_c(rhs)

@@ -114,3 +114,48 @@ class ProlongationOperator(BaseOperator):
         _lib.check(_lib.load().mg_op_prolong_bilinear(_lib.dtype_code(field.dtype), _lib.dtype_code(out.dtype),
                                                       coarse_grid.nx, coarse_grid.ny, _lib.ptr(field), _lib.ptr(out)))
         return out
+
+
+class DiffusionOperator(BaseOperator):
+    """A u = coefficient * div(a grad u)  (coefficient = -1: the SPD operator -div(a grad u)).
+
+    BASELINE config 5 names a variable-coefficient problem; the reference has no such operator (a README bullet
+    only), so this class and its discretisation are ours: `a` is sampled on the grid vertices
+    (array of grid.shape, or a callable a(X, Y)), face values are arithmetic means, coarse levels re-discretise with
+    `a` injected.  With a == 1 it reproduces LaplacianOperator(coefficient) bit for bit on dyadic grids."""
+
+    def __init__(self, a, coefficient=-1.0):
+        super().__init__(f"Diffusion(coeff={coefficient})")
+        self.a = a
+        self.coefficient = coefficient
+
+    def field(self, grid, dtype=None):
+        a = self.a(grid.X, grid.Y) if callable(self.a) else self.a
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), grid.shape), dtype=dtype or np.float64)
+        if np.any(a <= 0):
+            raise ValueError("the diffusion coefficient must be positive")
+        return a
+
+    def can_apply(self, grid):
+        return grid.nx >= 3 and grid.ny >= 3
+
+    def residual(self, grid, u, f):
+        u, f = _lib.as_c(u), _lib.as_c(f)
+        dt = np.result_type(u.dtype, f.dtype)
+        u, f = np.ascontiguousarray(u, dtype=dt), np.ascontiguousarray(f, dtype=dt)
+        if u.shape != grid.shape or f.shape != grid.shape:
+            raise ValueError(f"Field shape {u.shape} doesn't match grid shape {grid.shape}")
+        a = self.field(grid, dt)
+        r = np.empty_like(u)
+        _lib.check(_lib.load().mg_op_residual_var(_lib.dtype_code(dt), grid.nx, grid.ny, grid.hx, grid.hy,
+                                                  float(self.coefficient), _lib.ptr(a), _lib.ptr(u), _lib.ptr(f), _lib.ptr(r)))
+        grid.residual = r.copy()
+        return r
+
+    def apply(self, grid, field=None):
+        u = _lib.as_c(grid.values if field is None else field)
+        zero = np.zeros_like(u)
+        saved = grid._residual
+        out = -self.residual(grid, u, zero)          # A u = -(0 - A u); boundary rows/cols are 0 like LaplacianOperator.apply
+        grid._residual = saved
+        return out

@@ -131,6 +131,12 @@ class JacobiSmoother(IterativeSolver):                                       # s
     def smooth(self, grid, operator, u, rhs, num_iterations=1):
         u, rhs = self._prep(grid, u, rhs)
         out = np.empty_like(u)
+        if hasattr(operator, "field"):                 # DiffusionOperator: variable-coefficient Jacobi
+            a = operator.field(grid, u.dtype)
+            _lib.check(_lib.load().mg_op_jacobi_var(_lib.dtype_code(u.dtype), grid.nx, grid.ny, grid.hx, grid.hy,
+                                                    float(self.omega), int(num_iterations), _lib.ptr(a), _lib.ptr(u),
+                                                    _lib.ptr(rhs), _lib.ptr(out)))
+            return out
         _lib.check(_lib.load().mg_op_jacobi(_lib.dtype_code(u.dtype), grid.nx, grid.ny, grid.hx, grid.hy,
                                             float(self.omega), int(num_iterations), _lib.ptr(u), _lib.ptr(rhs),
                                             _lib.ptr(out)))
@@ -165,7 +171,11 @@ class GaussSeidelSmoother(IterativeSolver):                                  # s
         u, rhs = self._prep(grid, u, rhs)
         out = np.empty_like(u)
         lib = _lib.load()
-        if self.red_black:
+        if self.red_black and hasattr(operator, "field"):      # DiffusionOperator: variable-coefficient red-black GS
+            a = operator.field(grid, u.dtype)
+            _lib.check(lib.mg_op_rbgs_var(_lib.dtype_code(u.dtype), grid.nx, grid.ny, grid.hx, grid.hy, float(self.omega),
+                                          int(num_iterations), _lib.ptr(a), _lib.ptr(u), _lib.ptr(rhs), _lib.ptr(out)))
+        elif self.red_black:
             _lib.check(lib.mg_op_rbgs(_lib.dtype_code(u.dtype), grid.nx, grid.ny, grid.hx, grid.hy,
                                       float(self.omega), int(num_iterations), _lib.ptr(u), _lib.ptr(rhs),
                                       _lib.ptr(out)))

@@ -85,6 +85,7 @@ class MultigridSolver(BaseSolver):
                                                                   tolerance=self.coarse_tolerance)
         self._build_hierarchy(fine_grid, operator, restriction_op, prolongation_op)
         self._setup_args = (fine_grid, coeff)
+        self._coefficient_field = operator.field(fine_grid) if hasattr(operator, "field") else None
         for e in self._engines.values():
             e.close()
         self._engines = {}
@@ -121,6 +122,8 @@ class MultigridSolver(BaseSolver):
                 self.pre_smooth_iterations, self.post_smooth_iterations, self.smoother.kind, self.smoother.omega,
                 self.coarse_tolerance, self.coarse_max_iterations, prec, thr, mem, ref_rule,
                 self.device_id, self.profile)
+            if self._coefficient_field is not None:
+                self._engines[key].set_coefficient(self._coefficient_field)
         return self._engines[key]
 
     # -- solve (solvers/multigrid.py:184-251) -------------------------------------------------

@@ -357,6 +357,122 @@ class MGOracle:
                    "num_levels": len(self.shapes), "grid_hierarchy": list(self.shapes)}
 
 
+# --------------------------------------------------------------------------
+# Variable-coefficient operator  A u = coeff * div(a grad u)  -- NOT in the reference (README
+# bullet only).  PARITY UNPINNED: this is a restatement of OUR discretisation (csrc/mg_kernels.hpp varcoef_kernel),
+# checked by (i) a == 1 reproducing the constant-coefficient functions above bit for bit on dyadic grids and
+# (ii) second-order convergence on a manufactured solution.
+#   face values: arithmetic means of the vertex values; coarse operators: a injected (re-discretisation).
+# --------------------------------------------------------------------------
+
+def _faces(a):
+    c = a[1:-1, 1:-1]
+    return 0.5 * (c + a[2:, 1:-1]), 0.5 * (c + a[:-2, 1:-1]), 0.5 * (c + a[1:-1, 2:]), 0.5 * (c + a[1:-1, :-2])
+
+
+def var_residual(u, f, a, hx, hy, coeff=-1.0):
+    ihx2, ihy2 = 1.0 / (hx * hx), 1.0 / (hy * hy)
+    aip, aim, ajp, ajm = _faces(a)
+    sx = aip * u[2:, 1:-1] + aim * u[:-2, 1:-1]
+    sy = ajp * u[1:-1, 2:] + ajm * u[1:-1, :-2]
+    D = (aip + aim) * ihx2 + (ajp + ajm) * ihy2
+    r = f.copy()
+    r[1:-1, 1:-1] = f[1:-1, 1:-1] - coeff * ((sx * ihx2 + sy * ihy2) - u[1:-1, 1:-1] * D)
+    return r
+
+
+def _var_update(u, f, a, hx, hy, omega):
+    ihx2, ihy2 = 1.0 / (hx * hx), 1.0 / (hy * hy)
+    aip, aim, ajp, ajm = _faces(a)
+    sx = aip * u[2:, 1:-1] + aim * u[:-2, 1:-1]
+    sy = ajp * u[1:-1, 2:] + ajm * u[1:-1, :-2]
+    D = (aip + aim) * ihx2 + (ajp + ajm) * ihy2
+    un = (f[1:-1, 1:-1] + (ihx2 * sx + ihy2 * sy)) / D
+    return (1.0 - omega) * u[1:-1, 1:-1] + omega * un
+
+
+def var_jacobi(u, f, a, hx, hy, omega, nu=1):
+    u = u.copy()
+    for _ in range(nu):
+        u[1:-1, 1:-1] = _var_update(u, f, a, hx, hy, omega)
+    return u
+
+
+def var_rbgs(u, f, a, hx, hy, omega=1.0, nu=1):
+    u = u.copy()
+    masks = (_colour_mask(u.shape, 0), _colour_mask(u.shape, 1))
+    for _ in range(nu):
+        for m in masks:
+            upd = _var_update(u, f, a, hx, hy, omega)
+            inner = u[1:-1, 1:-1]
+            inner[m] = upd[m]
+    return u
+
+
+def var_lexgs_sweep(u, f, a, hx, hy):
+    nx, ny = u.shape
+    hx2, hy2 = hx * hx, hy * hy
+    for s in range(2, nx + ny - 3):
+        i = np.arange(max(1, s - (ny - 2)), min(nx - 2, s - 1) + 1)
+        j = s - i
+        aip, aim = 0.5 * (a[i, j] + a[i + 1, j]), 0.5 * (a[i, j] + a[i - 1, j])
+        ajp, ajm = 0.5 * (a[i, j] + a[i, j + 1]), 0.5 * (a[i, j] + a[i, j - 1])
+        nb = (aip * u[i + 1, j] + aim * u[i - 1, j]) / hx2 + (ajp * u[i, j + 1] + ajm * u[i, j - 1]) / hy2
+        D = (aip + aim) / hx2 + (ajp + ajm) / hy2
+        u[i, j] = (1 - 1.0) * u[i, j] + 1.0 * ((f[i, j] + nb) / D)
+    return u
+
+
+def var_coarse_residual(u, f, a, hx, hy, coeff):
+    hx2, hy2 = hx * hx, hy * hy
+    aip, aim, ajp, ajm = _faces(a)
+    D = (aip + aim) / hx2 + (ajp + ajm) / hy2
+    r = f.copy()
+    r[1:-1, 1:-1] = f[1:-1, 1:-1] - coeff * (((aip * u[2:, 1:-1] + aim * u[:-2, 1:-1]) / hx2 +
+                                               (ajp * u[1:-1, 2:] + ajm * u[1:-1, :-2]) / hy2) - u[1:-1, 1:-1] * D)
+    return r
+
+
+class VarMGOracle(MGOracle):
+    """MGOracle with A = coeff * div(a grad .): same cycle, variable-coefficient smoother / residual / coarsest solve."""
+
+    def __init__(self, a, *args, **kw):
+        super().__init__(a.shape[0], a.shape[1], *args, **kw)
+        self.a = [np.asarray(a, dtype=self.dtype)]
+        for _ in self.shapes[1:]:
+            self.a.append(self.a[-1][::2, ::2].copy())
+
+    def _smooth(self, u, level, nu):
+        hx, hy = self.h[level]
+        if self.smoother == "jacobi":
+            return var_jacobi(u, self.rhs[level], self.a[level], hx, hy, self.omega, nu)
+        return var_rbgs(u, self.rhs[level], self.a[level], hx, hy, self.omega, nu)
+
+    def residual_norm(self, u, rhs, level=0):
+        hx, hy = self.h[level]
+        return float(l2_norm(var_residual(u, rhs, self.a[level], hx, hy, self.coeff), hx, hy))
+
+    def cycle_once(self, u, level=0, pm=None):
+        L = len(self.shapes)
+        hx, hy = self.h[level]
+        if level == L - 1:
+            u = u.copy()
+            for it in range(1, self.cmaxit + 1):
+                var_lexgs_sweep(u, self.rhs[level], self.a[level], hx, hy)
+                if l2_norm(var_coarse_residual(u, self.rhs[level], self.a[level], hx, hy, self.coeff), hx, hy) < self.ctol:
+                    break
+            return u
+        u = self._smooth(u, level, self.pre)
+        r = var_residual(u, self.rhs[level], self.a[level], hx, hy, self.coeff)
+        self.rhs[level + 1] = restrict_fw(r, self.dtype).copy()
+        e = np.zeros_like(self.rhs[level + 1])
+        reps = 1 if self.cycle == "V" else 2 if self.cycle == "W" else max(1, 2 ** (L - level - 2))
+        for _ in range(reps):
+            e = self.cycle_once(e, level + 1)
+        u += prolong_bilinear(e, self.dtype)
+        return self._smooth(u, level, self.post)
+
+
 def sine_rhs(nx, ny, domain=(0.0, 1.0, 0.0, 1.0), dtype=np.float64):
     """f = 2 pi^2 sin(pi x) sin(pi y) on Grid.X/Grid.Y (README.md:77-78,
     gpu/gpu_benchmark.py:179-184); linspace in `dtype` as core/grid.py:48-50."""
