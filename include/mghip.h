@@ -79,6 +79,8 @@ typedef struct mg_config {
                                 two launches per level, identical arithmetic); 0: one launch per operator */
   int32_t tail;              /* with fused = 1 -- 1: all levels of <= ~65^2 cells incl. the coarsest solve run in ONE
                                 workgroup with their fields in LDS (one launch per visit); 0: per-level launches */
+  int32_t fmg_cycles;        /* > 0: mg_solve without an initial guess starts from a full-multigrid guess with this many
+                                cycles per level (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:583-652) */
   int32_t speculate;         /* with fused = 1 -- 1: mg_iterate / mg_solve queue the down leg of cycle k+1 while ||r_k||
                                 travels to the host (dropped if that norm ends the solve); 0: strictly one cycle at a time */
 } mg_config;
@@ -136,6 +138,8 @@ int mg_set_rhs(mg_handle* h, const void* rhs, int host_dtype);
 int mg_set_solution(mg_handle* h, const void* u0_or_null, int host_dtype);
 int mg_get_solution(mg_handle* h, void* u_out, int host_dtype);
 int mg_cycle(mg_handle* h, int ncycles);           /* asynchronous on the handle's stream        */
+/* full-multigrid initial guess from the resident rhs (replaces solvers/advanced_multigrid.py:626-683), asynchronous */
+int mg_fmg(mg_handle* h, int cycles_per_level);
 int mg_residual_norm(mg_handle* h, double* out);   /* sqrt(hx*hy*sum r^2), synchronises           */
 int mg_set_working_precision(mg_handle* h, int dtype); /* MG_PREC_ADAPTIVE only: in-device cast of u */
 int mg_synchronize(mg_handle* h);

@@ -30,7 +30,7 @@ class MgConfig(C.Structure):
         ("switch_threshold", C.c_double), ("memory_threshold_gb", C.c_double),
         ("adaptive_reference_rule", C.c_int32),
         ("device", C.c_int32), ("profile", C.c_int32), ("colour_offset", C.c_int32), ("fused", C.c_int32),
-        ("tail", C.c_int32), ("speculate", C.c_int32),
+        ("tail", C.c_int32), ("fmg_cycles", C.c_int32), ("speculate", C.c_int32),
     ]
 
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "mg_set_solution": (_i, [_vp, _vp, _i]),
     "mg_get_solution": (_i, [_vp, _vp, _i]),
     "mg_cycle": (_i, [_vp, _i]),
+    "mg_fmg": (_i, [_vp, _i]),
     "mg_residual_norm": (_i, [_vp, _pd]),
     "mg_set_working_precision": (_i, [_vp, _i]),
     "mg_synchronize": (_i, [_vp]),

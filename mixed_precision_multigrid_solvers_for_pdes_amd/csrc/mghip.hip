@@ -767,6 +767,56 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   return MG_OK;
 }
 
+// Full-multigrid initial guess (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:603-652): restrict the rhs to
+// every level (full weighting), solve the coarsest level from zero, then walk up: u_l = P u_{l+1}, followed by
+// `ncyc` cycles of the sub-hierarchy that starts at level l.  The boundary ring of the fine iterate (Dirichlet data)
+// is kept; coarser rings are zero.
+int fmg_init(mg_handle* h, int ncyc) {
+  const int L = h->L();
+  if (L < 2) return MG_OK;
+  h->norm_partials = 0;
+  for (int l = 0; l + 1 < L; ++l) {
+    Level& f = h->lv[l];
+    Level& c = h->lv[l + 1];
+    const int dt = h->level_dtype(l), dc = h->level_dtype(l + 1);
+    d_restrict(dt, dc, f.rhs[dt], c.rhs[dc], f.nx, f.ny, f.ld[dt], c.ld[dc], h->stream);
+  }
+  {
+    Level& v = h->lv[L - 1];
+    const int dt = h->level_dtype(L - 1);
+    (void)hipMemsetAsync(v.u[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream);
+    coarse_solve(h, L - 1, false);
+  }
+  for (int l = L - 2; l >= 0; --l) {
+    Level& f = h->lv[l];
+    Level& c = h->lv[l + 1];
+    const int dt = h->level_dtype(l), dc = h->level_dtype(l + 1);
+    const size_t bytes = (size_t)f.nx * f.ld[dt] * esize(dt);
+    if (l > 0) {
+      (void)hipMemsetAsync(f.u[dt], 0, bytes, h->stream);
+      if (f.t[dt]) (void)hipMemsetAsync(f.t[dt], 0, bytes, h->stream);
+    } else {
+      // keep the Dirichlet ring: zero the interior by a residual-free trick -- u0 := ring only.  The ping-pong
+      // partner t already carries the ring (set_u_impl); copy it back, interior cells are overwritten below.
+      if (f.t[dt]) { HIPC(&h->err, hipMemcpyAsync(f.u[dt], f.t[dt], bytes, hipMemcpyDeviceToDevice, h->stream)); }
+    }
+    // interior cells: u = P e  (ADD = false writes every cell the interpolation defines, ring included: e ring is 0)
+    if (l > 0) {
+      if (d_prolong<false>(dc, dt, h->grid_dtype, c.u[dc], f.u[dt], f.nx, f.ny, f.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE;
+    } else {
+      // level 0: u = ring + P e on the interior == (ring-only field) + P e everywhere, because (P e)[ring] = 0
+      if (d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], f.u[dt], f.nx, f.ny, f.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE;
+    }
+    for (int k = 0; k < ncyc; ++k) {
+      const int rc = (h->fused()) ? cycle_fused(h, l, false) : cycle(h, l);
+      if (rc != MG_OK) return rc;
+    }
+  }
+  h->norm_partials = 0;
+  HIPC(&h->err, hipGetLastError());
+  return MG_OK;
+}
+
 int run_cycle(mg_handle* h) {
   h->norm_partials = 0;
   if (h->fused() && h->L() > 1) return cycle_fused(h, 0, false);
@@ -1196,6 +1246,15 @@ int mg_get_solution(mg_handle* h, void* u_out, int host_dtype) {
   return download(&h->err, u_out, host_dtype, v.u[dt], dt, v.ld[dt], v.nx, v.ny, h->staging, h->stream);
 }
 
+int mg_fmg(mg_handle* h, int cycles_per_level) {
+  if (!h || cycles_per_level < 0) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_fmg: bad argument");
+  if (!h->have_rhs) return fail(&h->err, MG_ERR_STATE, "mg_fmg before mg_set_rhs");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  const int rc = fmg_init(h, cycles_per_level);
+  if (rc != MG_OK) return fail(&h->err, rc, "mg_fmg: unsupported precision combination");
+  return MG_OK;
+}
+
 int mg_cycle(mg_handle* h, int ncycles) {
   if (!h || ncycles < 0) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_cycle: bad argument");
   if (!h->have_rhs) return fail(&h->err, MG_ERR_STATE, "mg_cycle before mg_set_rhs");
@@ -1338,6 +1397,9 @@ int mg_solve(mg_handle* h, const void* rhs, const void* u0, void* u_out, int hos
   rc = set_u_impl(h, u0, host_dtype);
   if (rc != MG_OK) return rc;
   st.h2d_seconds = now_s() - t0;
+  if (h->cfg.fmg_cycles > 0 && !u0) {                        // gpu/gpu_solver.py:583: FMG only without an initial guess
+    if ((rc = fmg_init(h, h->cfg.fmg_cycles)) != MG_OK) return fail(&h->err, rc, "fmg: unsupported precision combination");
+  }
   rc = iterate_impl(h, tol, max_iter, hist, hist_cap, n_iter, converged, prec_hist, &st);
   if (rc != MG_OK) return rc;
   t0 = now_s();

@@ -110,7 +110,7 @@ class MixedPrecisionMultigrid:
     def __init__(self, precision_strategy="adaptive", switch_threshold=1e-6, use_gpu=True, max_levels=None,
                  max_iterations=50, tolerance=1e-8, cycle_type="V", pre_smooth_iterations=2,
                  post_smooth_iterations=2, smoother="jacobi", relaxation_parameter=None, device_id=0,
-                 coarse_tolerance=1e-12, coarse_max_iterations=1000):
+                 coarse_tolerance=1e-12, coarse_max_iterations=1000, use_fmg=False, fmg_cycles=1):
         if precision_strategy not in self.STRATEGIES:
             raise ValueError(f"Unknown precision strategy: {precision_strategy}")
         if smoother not in ("jacobi", "gauss_seidel", "red_black", "sor"):
@@ -126,6 +126,7 @@ class MixedPrecisionMultigrid:
         self.omega = relaxation_parameter
         self.device_id = device_id
         self.coarse_tolerance, self.coarse_max_iterations = coarse_tolerance, coarse_max_iterations
+        self.use_fmg, self.fmg_cycles = use_fmg, fmg_cycles
         if use_gpu:
             _lib.load()                                 # fail at construction, not at first solve
             if _lib.device_count() <= device_id:
@@ -163,7 +164,8 @@ class MixedPrecisionMultigrid:
         if self.use_gpu:
             grid = problem.grid(dtype)
             solver = MultigridSolver(levels, self.max_iterations, self.tolerance, self.cycle_type, self.pre, self.post,
-                                     self.coarse_tolerance, self.coarse_max_iterations, device_id=self.device_id)
+                                     self.coarse_tolerance, self.coarse_max_iterations, device_id=self.device_id,
+                                     fmg_cycles=self.fmg_cycles if self.use_fmg else 0)
             solver.setup(grid, LaplacianOperator(coefficient=-1.0), RestrictionOperator("full_weighting"),
                          ProlongationOperator("bilinear"), smoother=self._smoother())
             try:

@@ -40,7 +40,7 @@ def _precision_config(grid, pm):
 class MultigridSolver(BaseSolver):
     def __init__(self, max_levels=4, max_iterations=50, tolerance=1e-8, cycle_type=MultigridCycle.V_CYCLE,
                  pre_smooth_iterations=2, post_smooth_iterations=2, coarse_tolerance=1e-12,
-                 coarse_max_iterations=1000, verbose=False, device_id=0, profile=False):
+                 coarse_max_iterations=1000, verbose=False, device_id=0, profile=False, fmg_cycles=0):
         super().__init__(max_iterations, tolerance, verbose, "Multigrid")
         self.max_levels = max_levels
         self.cycle_type = cycle_type
@@ -50,6 +50,7 @@ class MultigridSolver(BaseSolver):
         self.coarse_max_iterations = coarse_max_iterations
         self.device_id = device_id
         self.profile = profile
+        self.fmg_cycles = fmg_cycles      # > 0: start from a full-multigrid guess when no initial guess is given
         self.grids = []
         self.operators, self.restriction_ops, self.prolongation_ops = [], [], []
         self.smoother = None
@@ -121,7 +122,7 @@ class MultigridSolver(BaseSolver):
                 g.nx, g.ny, g.domain, self._setup_args[1], self.max_levels, self.cycle_type,
                 self.pre_smooth_iterations, self.post_smooth_iterations, self.smoother.kind, self.smoother.omega,
                 self.coarse_tolerance, self.coarse_max_iterations, prec, thr, mem, ref_rule,
-                self.device_id, self.profile)
+                self.device_id, self.profile, fmg_cycles=self.fmg_cycles)
             if self._coefficient_field is not None:
                 self._engines[key].set_coefficient(self._coefficient_field)
         return self._engines[key]

@@ -335,6 +335,27 @@ class MGOracle:
             u = self._smooth(u, level, self.post)
         return u
 
+    # -- full-multigrid initial guess (advanced_multigrid.py:626-683) ---------
+    def fmg_init(self, rhs, cycles=1, ring=None):
+        """Restrict rhs to every level (full weighting), solve the coarsest level from zero, then per level upward:
+        u = P u_coarse followed by `cycles` cycles of the sub-hierarchy starting at that level.  `ring`: Dirichlet
+        data kept on the finest boundary (our extension; the reference overwrites it with zeros)."""
+        L = len(self.shapes)
+        hier = [rhs.copy()]
+        for _ in range(L - 1):
+            hier.append(restrict_fw(hier[-1], self.dtype))
+        self.rhs[L - 1] = hier[-1].copy()
+        hx, hy = self.h[L - 1]
+        u, _ = coarse_solve(np.zeros_like(hier[-1]), hier[-1], hx, hy, self.coeff, self.ctol, self.cmaxit)
+        for level in range(L - 2, -1, -1):
+            u = prolong_bilinear(u, self.dtype)
+            if level == 0 and ring is not None:
+                u[0, :], u[-1, :], u[:, 0], u[:, -1] = ring[0, :], ring[-1, :], ring[:, 0], ring[:, -1]
+            self.rhs[level] = hier[level].copy()
+            for _ in range(cycles):
+                u = self.cycle_once(u, level)
+        return u
+
     # -- outer loop (multigrid.py:184-251) ---------------------------------
     def solve(self, rhs, u0=None, tol=1e-8, max_iterations=50, pm=None):
         u = np.zeros_like(rhs) if u0 is None else u0.copy()

@@ -68,7 +68,7 @@ def test_product_path_fails_loudly_without_device():
 def test_argument_validation_needs_no_device():
     import ctypes as C
     lib = _lib.load()
-    cfg = _lib.MgConfig(2, 17, 0, 1, 0, 1, -1.0, 4, 0, 2, 2, 0, 0.8, 1e-12, 1000, 0, 1e-6, 4.0, 0, 0, 0, 0, 1, 1, 1)
+    cfg = _lib.MgConfig(2, 17, 0, 1, 0, 1, -1.0, 4, 0, 2, 2, 0, 0.8, 1e-12, 1000, 0, 1e-6, 4.0, 0, 0, 0, 0, 1, 1, 0, 1)
     h = C.c_void_p(None)
     assert lib.mg_create(C.byref(cfg), C.byref(h)) == _lib.MG_ERR_INVALID_VALUE
     assert b"at least 3 points" in lib.mg_last_error(None)
