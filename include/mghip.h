@@ -204,6 +204,24 @@ int mg_dev_restrict_fw(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, i
 int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int nxf, int nyf, int ldf, int nxc,
                        int nyc, int ldc, int sides, const void* coarse, void* fine_u, void* stream);
 int mg_dev_convert(int in_dtype, int out_dtype, int nx, int ny, int ldi, int ldo, const void* in, void* out, void* stream);
+/* Fused legs on device arrays (the kernels of the single-GPU engine).  On a sub-domain the local
+ * array carries a ghost zone several cells wide: every edge is treated as fixed, so after s sweeps the outer s cells
+ * of a ghost zone are stale -- the caller sizes the zone so that the cells it owns stay exact.  Coarse cell (ic, jc)
+ * sits on fine cell (2 (ic - ci_off), 2 (jc - cj_off)).
+ *   down leg: nsweep (<= 2) sweeps of u (or of the zero iterate: zero_init) -> out; residual; full weighting into the
+ *             interior cells of rhs_coarse that have a complete fine neighbourhood here.
+ *   up leg:   out = sweeps(u + P e_coarse); with norm != 0 also *sumsq_dev = sum of r^2 over cells
+ *             [ni_lo, ni_hi) x [nj_lo, nj_hi) that are interior to this array (scratch >= mg_dev_scratch_bytes()). */
+int mg_dev_down_leg(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
+                    int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
+                    const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream);
+int mg_dev_up_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
+                  int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
+                  const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
+                  int nj_hi, void* scratch, double* sumsq_dev, void* stream);
+/* boundary ring of a coarse field := injected fine values, on the physical edges (`sides`) only */
+int mg_dev_inject_ring(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides, int ci_off,
+                       int cj_off, const void* fine, void* coarse, void* stream);
 int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes);
 /* pitch (elements) the library itself uses for an (nx, ny) field of `dtype` */
 int mg_pitch_elems(int dtype, int ny, int* ld);

@@ -396,17 +396,20 @@ __global__ __launch_bounds__(kBlock) void restrict_fw_kernel(const TIN* __restri
 //   reference: operators/transfer.py:239-265; far-edge zeros (F9) on physical far edges (`sides`).
 template <typename TX, typename TC, int N>
 __device__ __forceinline__ void prolong_vec(const TX* __restrict__ e, int ldc, int nxc, int nyc, int gi, int gj0,
-                                            int nxf, int nyf, int sides, TC (&val)[N], bool (&ok)[N]) {
+                                            int nxf, int nyf, int sides, TC (&val)[N], bool (&ok)[N], int ci_off = 0,
+                                            int cj_off = 0) {
+  // ci_off / cj_off: coarse cell (ic, jc) sits on fine cell (2 (ic - ci_off), 2 (jc - cj_off)) -- non-zero on
+  // sub-domains whose coarse array carries a wider ghost zone (in fine units) than the fine one
   constexpr int M = N / 2 + 1;
-  const int ic = gi >> 1, jc0 = gj0 >> 1;
+  const int ic = (gi >> 1) + ci_off, jc0 = (gj0 >> 1) + cj_off;
   const bool iodd = gi & 1;
-  const bool row_ok = (ic + (iodd ? 1 : 0)) < nxc;
-  const TX* r0 = e + (size_t)ic * ldc + jc0;
+  const bool row_ok = ic >= 0 && (ic + (iodd ? 1 : 0)) < nxc;
+  const TX* r0 = e + (size_t)(row_ok ? ic : 0) * ldc + jc0;
   const TX* r1 = r0 + ((iodd && row_ok) ? ldc : 0);
   TC a[M], b[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
-    const bool in = row_ok && (jc0 + m < nyc);
+    const bool in = row_ok && (jc0 + m >= 0) && (jc0 + m < nyc);
     a[m] = in ? (TC)r0[m] : TC(0);
     b[m] = in ? (TC)r1[m] : TC(0);
   }
@@ -414,10 +417,10 @@ __device__ __forceinline__ void prolong_vec(const TX* __restrict__ e, int ldc, i
   for (int k = 0; k < N; ++k) {
     const int j = gj0 + k, m = k >> 1;
     if ((k & 1) == 0) {
-      ok[k] = row_ok && (j < nyf) && (jc0 + m < nyc);
+      ok[k] = row_ok && (j < nyf) && (jc0 + m >= 0) && (jc0 + m < nyc);
       val[k] = iodd ? (((sides & kSideJHi) && j == nyf - 1) ? TC(0) : TC(0.5) * (a[m] + b[m])) : a[m];
     } else {
-      ok[k] = row_ok && (j < nyf) && (jc0 + m + 1 < nyc);
+      ok[k] = row_ok && (j < nyf) && (jc0 + m >= 0) && (jc0 + m + 1 < nyc);
       val[k] = iodd ? TC(0.25) * (((a[m] + a[m + 1]) + b[m]) + b[m + 1])
                     : (((sides & kSideIHi) && gi == nxf - 1) ? TC(0) : TC(0.5) * (a[m] + a[m + 1]));
     }
@@ -1125,6 +1128,9 @@ struct FusedArgs {
   int colour_offset;            // parity of the global index of local cell (0,0) (red-black colouring)
   int use_div;                  // 1: divide by the diagonal (1/D not exact)
   int nxc, nyc, ldc;            // coarse level (restriction target / prolongation source)
+  int ci_off, cj_off;           // coarse (ic, jc) <-> fine (2 (ic - ci_off), 2 (jc - cj_off)); 0 for whole grids
+  int sides;                    // physical-boundary edges of this array (far-edge rule of the prolongation)
+  int ni_lo, ni_hi, nj_lo, nj_hi;   // cells counted by the norm stage (whole grid: the interior)
 };
 
 template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM>
@@ -1166,7 +1172,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
         using TS = typename std::conditional<(sizeof(TC) > sizeof(T)), TC, T>::type;
         TC val[N];
         bool ok[N];
-        prolong_vec<TX, TC, N>(e_coarse, a.ldc, a.nxc, a.nyc, gi, gj0, a.nx, a.ny, kAllSides, val, ok);
+        prolong_vec<TX, TC, N>(e_coarse, a.ldc, a.nxc, a.nyc, gi, gj0, a.nx, a.ny, a.sides, val, ok, a.ci_off, a.cj_off);
 #pragma unroll
         for (int e = 0; e < N; ++e)
           if (ok[e]) uu.v[e] = (T)((TS)uu.v[e] + (TS)val[e]);
@@ -1283,7 +1289,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
           const int gj = gj0 + e;
           if (gj >= 1 && gj < a.ny - 1) {
             o.v[e] = f[k].v[e] - au;
-            if (POST == kPostNorm) acc += (double)o.v[e] * (double)o.v[e];
+            if (POST == kPostNorm && gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi) acc += (double)o.v[e] * (double)o.v[e];
           }
         }
       }
@@ -1305,8 +1311,9 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   for (int c = threadIdx.x; c < CI * CJ; c += kFusedBlock) {
     const int ci = c / CJ, cj = c - ci * CJ;
     const int fi = i0 + 1 + 2 * ci, fj = j0 + 2 * cj;  // i0 is odd: even fine rows are i0+1, i0+3, ...
-    const int ic = fi >> 1, jc = fj >> 1;
+    const int ic = (fi >> 1) + a.ci_off, jc = (fj >> 1) + a.cj_off;
     if (ic < 1 || ic > a.nxc - 2 || jc < 1 || jc > a.nyc - 2) continue;
+    if (fi < 1 || fi > a.nx - 2 || fj < 1 || fj > a.ny - 2) continue;     // coarse cell without a full fine neighbourhood here
     const T* p = dst + (fi - ri0) * S::RJ + (fj - rj0);
     const T corners = ((p[-S::RJ - 1] + p[-S::RJ + 1]) + p[S::RJ - 1]) + p[S::RJ + 1];
     const T edges = ((p[-S::RJ] + p[S::RJ]) + p[-1]) + p[1];
@@ -1318,15 +1325,19 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
 // r = f on boundary cells this ring of every coarse rhs is constant over a solve: written once per rhs.
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(kBlock) void inject_ring_kernel(const TIN* __restrict__ fine, TOUT* __restrict__ coarse,
-                                                             int ldf, int nxc, int nyc, int ldc) {
+                                                             int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides,
+                                                             int ci_off, int cj_off) {
   const int ring = 2 * nxc + 2 * nyc;
   for (int t = blockIdx.x * kBlock + threadIdx.x; t < ring; t += gridDim.x * kBlock) {
-    int ic, jc;
-    if (t < nyc) { ic = 0; jc = t; }
-    else if (t < 2 * nyc) { ic = nxc - 1; jc = t - nyc; }
-    else if (t < 2 * nyc + nxc) { ic = t - 2 * nyc; jc = 0; }
-    else { ic = t - 2 * nyc - nxc; jc = nyc - 1; }
-    coarse[(size_t)ic * ldc + jc] = (TOUT)fine[(size_t)(2 * ic) * ldf + 2 * jc];
+    int ic, jc, side;
+    if (t < nyc) { ic = 0; jc = t; side = kSideILo; }
+    else if (t < 2 * nyc) { ic = nxc - 1; jc = t - nyc; side = kSideIHi; }
+    else if (t < 2 * nyc + nxc) { ic = t - 2 * nyc; jc = 0; side = kSideJLo; }
+    else { ic = t - 2 * nyc - nxc; jc = nyc - 1; side = kSideJHi; }
+    if (!(sides & side)) continue;                       // a ghost edge of a sub-domain: not a boundary
+    const int fi = 2 * (ic - ci_off), fj = 2 * (jc - cj_off);
+    if (fi < 0 || fi >= nxf || fj < 0 || fj >= nyf) continue;
+    coarse[(size_t)ic * ldc + jc] = (TOUT)fine[(size_t)fi * ldf + fj];
   }
 }
 

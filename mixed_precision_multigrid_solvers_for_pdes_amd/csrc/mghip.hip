@@ -284,6 +284,7 @@ void d_inject(int di, int dout, const void* fine, void* coarse, int ldf, int nxc
 }
 
 // ------------------------------------------------------------------ fused legs ----------------
+struct LegGeom;
 template <typename T, int HALO>
 mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int nxc, int nyc, int ldc, int poff) {
   using S = mg::FusedShape<T, HALO>;
@@ -295,6 +296,8 @@ mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int n
   a.ntiles = tiles_i * a.tiles_j;
   a.nsweep = nsweep; a.use_div = use_div ? 1 : 0; a.colour_offset = poff & 1;
   a.nxc = nxc; a.nyc = nyc; a.ldc = ldc;
+  a.ci_off = a.cj_off = 0; a.sides = mg::kAllSides;
+  a.ni_lo = 1; a.ni_hi = nx - 1; a.nj_lo = 1; a.nj_hi = ny - 1;
   return a;
 }
 
@@ -303,14 +306,22 @@ struct LegGeom {      // what every fused launch needs
   double hx, hy, omega, coeff;
   int nsweep, poff;
   bool fine;
+  // sub-domain extras (defaults = whole grid)
+  int ci_off = 0, cj_off = 0, sides = mg::kAllSides;
+  int ni_lo = -1, ni_hi = -1, nj_lo = -1, nj_hi = -1;     // norm window; -1: the interior
 };
+inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
+  a.ci_off = g.ci_off; a.cj_off = g.cj_off; a.sides = g.sides;
+  if (g.ni_lo >= 0) { a.ni_lo = g.ni_lo; a.ni_hi = g.ni_hi; a.nj_lo = g.nj_lo; a.nj_hi = g.nj_hi; }
+}
 
 // down leg: nsweep sweeps + residual + full-weighting restriction (interior coarse cells).  TX = coarse rhs dtype.
 template <typename T, typename TX, int SM>
 void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
   constexpr int HALO = 2 * mg::sweep_halo(SM) + 2;
   const Coef c = coefs(g.hx, g.hy);
-  const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+  mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+  apply_sub(a, g);
   void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T);
   if (zero_init) k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM>
                             : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 0, SM>;
@@ -328,7 +339,8 @@ int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double
   const Coef c = coefs(g.hx, g.hy);
   if (norm) {
     constexpr int HALO = 2 * mg::sweep_halo(SM) + 1;
-    const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+    mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+    apply_sub(a, g);
     auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM>
                     : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 0, SM>;
     hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
@@ -336,7 +348,8 @@ int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double
     return a.ntiles;
   }
   constexpr int HALO = 2 * mg::sweep_halo(SM);
-  const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+  mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+  apply_sub(a, g);
   auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM>
                   : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 0, SM>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
@@ -395,16 +408,18 @@ void d_sweeps(int sm, int dt, const void* u, const void* rhs, void* out, const L
 }
 
 template <typename TI, typename TO>
-void launch_inject_ring(const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
+void launch_inject_ring(const void* fine, void* coarse, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides, int ci_off,
+                        int cj_off, hipStream_t st) {
   hipLaunchKernelGGL((mg::inject_ring_kernel<TI, TO>), dim3(grid_for(2 * (nxc + nyc))), dim3(mg::kBlock), 0, st,
-                     (const TI*)fine, (TO*)coarse, ldf, nxc, nyc, ldc);
+                     (const TI*)fine, (TO*)coarse, nxf, nyf, ldf, nxc, nyc, ldc, sides, ci_off, cj_off);
 }
 
-void d_inject_ring(int di, int dout, const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
-  if (di == MG_F32 && dout == MG_F32) launch_inject_ring<float, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
-  else if (di == MG_F64 && dout == MG_F64) launch_inject_ring<double, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
-  else if (di == MG_F64 && dout == MG_F32) launch_inject_ring<double, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
-  else launch_inject_ring<float, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
+void d_inject_ring(int di, int dout, const void* fine, void* coarse, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc,
+                   hipStream_t st, int sides = mg::kAllSides, int ci_off = 0, int cj_off = 0) {
+  if (di == MG_F32 && dout == MG_F32) launch_inject_ring<float, float>(fine, coarse, nxf, nyf, ldf, nxc, nyc, ldc, sides, ci_off, cj_off, st);
+  else if (di == MG_F64 && dout == MG_F64) launch_inject_ring<double, double>(fine, coarse, nxf, nyf, ldf, nxc, nyc, ldc, sides, ci_off, cj_off, st);
+  else if (di == MG_F64 && dout == MG_F32) launch_inject_ring<double, float>(fine, coarse, nxf, nyf, ldf, nxc, nyc, ldc, sides, ci_off, cj_off, st);
+  else launch_inject_ring<float, double>(fine, coarse, nxf, nyf, ldf, nxc, nyc, ldc, sides, ci_off, cj_off, st);
 }
 
 // ------------------------------------------------------------------ host <-> device helpers -----
@@ -956,7 +971,7 @@ void inject_rings(mg_handle* h, int ph) {
     Level& f = h->lv[l];
     Level& c = h->lv[l + 1];
     const int dt = h->level_dtype_in(l, ph), dc = h->level_dtype_in(l + 1, ph);
-    d_inject_ring(dt, dc, f.rhs[dt], c.rhs[dc], f.ld[dt], c.nx, c.ny, c.ld[dc], h->stream);
+    d_inject_ring(dt, dc, f.rhs[dt], c.rhs[dc], f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], h->stream);
   }
 }
 
@@ -1504,7 +1519,9 @@ int mg_dev_residual(int dtype, int nx, int ny, int ld, double hx, double hy, dou
 
 int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes) {
   CHECK_DEV(bytes && nx >= 1 && ny >= 1, "mg_dev_scratch_bytes: bad argument");
-  *bytes = (int64_t)sizeof(double) * 2048;
+  // one fp64 partial per workgroup: <= 2048 for the grid-stride reductions, one per 32 x 512-byte tile for the up leg
+  const int64_t tiles = ((int64_t)(nx + mg::kFusedTI - 1) / mg::kFusedTI + 1) * ((int64_t)(ny + 63) / 64 + 1);
+  *bytes = (int64_t)sizeof(double) * std::max<int64_t>(2048, tiles);
   return MG_OK;
 }
 
@@ -1536,6 +1553,45 @@ int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int 
   CHECK_DEV(ld_ok(fine_dtype, nyf, ldf) && ldc >= nyc && coarse && fine_u && aligned16(fine_u), "mg_dev_prolong_add: bad pitch / pointer");
   const int rc = d_prolong_sub<true>(coarse_dtype, fine_dtype, compute_dtype, coarse, fine_u, nxf, nyf, ldf, nxc, nyc, ldc, sides, (hipStream_t)stream);
   if (rc != MG_OK) return fail(nullptr, rc, "mg_dev_prolong_add: fp32 interpolation needs fp32 coarse and fine fields");
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+// ---- fused legs on device arrays (sub-domains: wide ghost zones, coarse offsets, norm window) --------------------
+int mg_dev_down_leg(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
+                    int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
+                    const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream) {
+  CHECK_DEV((smoother == MG_JACOBI || smoother == MG_RBGS) && valid_dtype(dtype) && valid_dtype(coarse_dtype), "mg_dev_down_leg: bad smoother / dtype");
+  CHECK_DEV(nx >= 3 && ny >= 3 && nxc >= 3 && nyc >= 3 && ld_ok(dtype, ny, ld) && ldc >= nyc && nsweep >= 0 && nsweep <= 2, "mg_dev_down_leg: bad shape / pitch / sweep count");
+  CHECK_DEV(rhs && out && rhs_coarse && (zero_init || u) && u != out && aligned16(rhs) && aligned16(out) && (!u || aligned16(u)), "mg_dev_down_leg: bad pointer");
+  LegGeom g{nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, colour_offset, false};
+  g.ci_off = ci_off; g.cj_off = cj_off;
+  d_down(smoother, dtype, coarse_dtype, u ? u : rhs, rhs, out, rhs_coarse, g, zero_init != 0, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_up_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
+                  int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
+                  const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
+                  int nj_hi, void* scratch, double* sumsq_dev, void* stream) {
+  CHECK_DEV((smoother == MG_JACOBI || smoother == MG_RBGS) && valid_dtype(dtype) && valid_dtype(coarse_dtype) && valid_dtype(compute_dtype), "mg_dev_up_leg: bad smoother / dtype");
+  CHECK_DEV(nx >= 3 && ny >= 3 && nxc >= 2 && nyc >= 2 && ld_ok(dtype, ny, ld) && ldc >= nyc && nsweep >= 0 && nsweep <= 2 && sides >= 0 && sides <= 15, "mg_dev_up_leg: bad shape / pitch / sweep count");
+  CHECK_DEV(u && rhs && out && e_coarse && u != out && aligned16(u) && aligned16(rhs) && aligned16(out) && (!norm || (scratch && sumsq_dev)), "mg_dev_up_leg: bad pointer");
+  LegGeom g{nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, colour_offset, false};
+  g.ci_off = ci_off; g.cj_off = cj_off; g.sides = sides;
+  if (norm) { g.ni_lo = ni_lo; g.ni_hi = ni_hi; g.nj_lo = nj_lo; g.nj_hi = nj_hi; }
+  const int n = d_up(smoother, dtype, coarse_dtype, compute_dtype, u, rhs, out, e_coarse, (double*)scratch, g, norm != 0, (hipStream_t)stream);
+  if (n < 0) return fail(nullptr, MG_ERR_INVALID_VALUE, "mg_dev_up_leg: fp32 interpolation needs fp32 coarse and fine fields");
+  if (norm) launch_reduce((double*)scratch, n, sumsq_dev, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_inject_ring(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides, int ci_off,
+                       int cj_off, const void* fine, void* coarse, void* stream) {
+  CHECK_DEV(valid_dtype(in_dtype) && valid_dtype(out_dtype) && nxf >= 3 && nyf >= 3 && nxc >= 2 && nyc >= 2 && ldf >= nyf && ldc >= nyc && fine && coarse && sides >= 0 && sides <= 15, "mg_dev_inject_ring: bad argument");
+  d_inject_ring(in_dtype, out_dtype, fine, coarse, nxf, nyf, ldf, nxc, nyc, ldc, (hipStream_t)stream, sides, ci_off, cj_off);
   HIPC(nullptr, hipGetLastError());
   return MG_OK;
 }

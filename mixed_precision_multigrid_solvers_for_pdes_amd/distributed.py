@@ -12,10 +12,17 @@ decomposition-invariant by construction:
     that is either the physical boundary or a ghost copy of the neighbour's edge.  Local cell (0,0) has
     an even global index, so coarse cell (ic, jc) sits on local fine cell (2ic, 2jc) on every rank and
     the red/black colouring is the global one;
-  * Jacobi / red-black GS update owned cells only (the kernels pass the ring through); every sweep
-    (every colour) is followed by a halo exchange of u; the residual gets one exchange (with corners)
-    before full-weighting restriction; prolongation interpolates the ghost ring from the exchanged
-    coarse ghost values, so no exchange is needed after the correction;
+  * mode "fused" (default; communication-avoiding): every rank keeps a ghost ZONE of G = 7 cells and runs the same
+    two fused kernels per level as the single-GPU engine (down leg: 2 sweeps + residual + restriction; up leg:
+    prolongation + 2 sweeps [+ norm]) on its whole local array, recomputing inside the ghost zone what the
+    neighbour computes too; each sweep / residual / transfer invalidates one more ghost cell from the outside,
+    and G = 7 is the smallest odd width for which the owned cells stay exact through a whole V(2,2) visit.
+    Exchanges per cycle: the fine iterate once (7 rows / columns per neighbour) and each coarse right-hand side
+    once -- L_d + 1 exchanges instead of 5 L_d, each a few hundred KB instead of 16 KB, and two launches per level;
+  * mode "per_operator": 1-cell ghost ring, one launch per operator (the kernels pass the ring through); every
+    sweep (every colour) is followed by a halo exchange of u; the residual gets one exchange (with corners)
+    before full-weighting restriction; prolongation interpolates the ghost ring from the exchanged coarse ghost
+    values, so no exchange is needed after the correction;
   * below `agglomerate_at` points per direction the remaining coarse hierarchy is solved redundantly on
     every GPU by the single-GPU engine after one all-gather of the coarse right-hand side: no broadcast
     back, no latency-bound tiny halo messages;
@@ -66,33 +73,46 @@ def process_grid(world):
 
 
 class Block:
-    """One rank's block of one level."""
+    """One rank's block of one level: owned cells, a ghost zone of `G` cells towards every neighbour, the physical
+    boundary row/column where the block touches the domain boundary.  Local (0, 0) has an even global index."""
 
-    def __init__(self, NX, NY, px, py, rx, ry):
+    def __init__(self, NX, NY, px, py, rx, ry, G=1):
         mx, my = (NX - 1) // px, (NY - 1) // py
-        self.NX, self.NY = NX, NY
-        self.gx0, self.gy0 = rx * mx, ry * my                   # global index of local (0, 0)
-        self.lnx = mx + (1 if rx == px - 1 else 2)
-        self.lny = my + (1 if ry == py - 1 else 2)
+        self.NX, self.NY, self.G = NX, NY, G
+        self.gx0 = 0 if rx == 0 else rx * mx - (G - 1)              # global index of local (0, 0)
+        self.gy0 = 0 if ry == 0 else ry * my - (G - 1)
+        gx1 = NX - 1 if rx == px - 1 else (rx + 1) * mx + G          # global index of the last local row
+        gy1 = NY - 1 if ry == py - 1 else (ry + 1) * my + G
+        self.lnx, self.lny = gx1 - self.gx0 + 1, gy1 - self.gy0 + 1
         self.sides = ((SIDE_ILO if rx == 0 else 0) | (SIDE_IHI if rx == px - 1 else 0) |
                       (SIDE_JLO if ry == 0 else 0) | (SIDE_JHI if ry == py - 1 else 0))
+        # owned interior cells (local indices, inclusive)
+        self.oi_lo = rx * mx + 1 - self.gx0
+        self.oi_hi = (NX - 2 if rx == px - 1 else (rx + 1) * mx) - self.gx0
+        self.oj_lo = ry * my + 1 - self.gy0
+        self.oj_hi = (NY - 2 if ry == py - 1 else (ry + 1) * my) - self.gy0
         # exclusive window: owned cells plus the adjacent physical boundary cells (a disjoint cover of the grid)
-        self.i_lo = 0 if rx == 0 else 1
-        self.i_hi = self.lnx if rx == px - 1 else self.lnx - 1
-        self.j_lo = 0 if ry == 0 else 1
-        self.j_hi = self.lny if ry == py - 1 else self.lny - 1
+        self.i_lo = 0 if rx == 0 else self.oi_lo
+        self.i_hi = self.lnx if rx == px - 1 else self.oi_hi + 1
+        self.j_lo = 0 if ry == 0 else self.oj_lo
+        self.j_hi = self.lny if ry == py - 1 else self.oj_hi + 1
+
+    def coarse_offsets(self, coarse):
+        """(ci_off, cj_off): coarse local (ic, jc) sits on fine local (2 (ic - ci_off), 2 (jc - cj_off))."""
+        return (self.gx0 - 2 * coarse.gx0) // 2, (self.gy0 - 2 * coarse.gy0) // 2
 
 
-def distributed_levels(shapes, px, py, agglomerate_at):
+def distributed_levels(shapes, px, py, agglomerate_at, G=1):
     """Number of leading levels that stay distributed.  A level is distributed while its cuts are even
-    (so the next level lines up), its blocks keep >= 4 owned rows/cols and it is larger than
+    (so the next level lines up), its blocks own at least max(4, G + 1) rows/cols and it is larger than
     `agglomerate_at` points in some direction; at least one level is always left for the replicated part."""
     n = 0
+    need = max(4, G + 1)
     for (NX, NY) in shapes[:-1]:
         if (NX - 1) % px or (NY - 1) % py:
             break
         mx, my = (NX - 1) // px, (NY - 1) // py
-        if (px > 1 and (mx % 2 or mx < 4)) or (py > 1 and (my % 2 or my < 4)):
+        if (px > 1 and (mx % 2 or mx < need)) or (py > 1 and (my % 2 or my < need)):
             break
         if max(NX, NY) <= agglomerate_at:
             break
@@ -120,7 +140,7 @@ class HipOps:
         self.tdtype = torch.float32 if self.dt == _lib.MG_F32 else torch.float64
         self.device = device
         nbytes = C.c_int64(0)
-        _lib.check(self.lib.mg_dev_scratch_bytes(8, 8, C.byref(nbytes)))
+        _lib.check(self.lib.mg_dev_scratch_bytes(16400, 16400, C.byref(nbytes)))      # enough for any block up to 16385^2
         self.scratch = torch.zeros(nbytes.value // 8, dtype=torch.float64, device=device)
         self.acc = torch.zeros(1, dtype=torch.float64, device=device)
         self._engine = None
@@ -163,6 +183,27 @@ class HipOps:
         _lib.check(self.lib.mg_dev_prolong_add(self.dt, self.dt, self.comp_dt, lnxf, lnyf, fine_u.stride(0), lnxc, lnyc,
                                                coarse.stride(0), sides, self._p(coarse), self._p(fine_u), self._stream()))
 
+    # fused legs (mode "fused"): the single-GPU engine's kernels on the local array with its ghost zone
+    def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff):
+        _lib.check(self.lib.mg_dev_down_leg(sm, self.dt, self.dt, lnx, lny, rhs.stride(0), lnxc, lnyc, rhs_c.stride(0), ci_off,
+                                            cj_off, hx, hy, omega, coeff, nsweep, int(zero_init), poff,
+                                            None if zero_init else self._p(u), self._p(rhs), self._p(out), self._p(rhs_c),
+                                            self._stream()))
+
+    def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff,
+               window=None):
+        """out = sweeps(u + P e_c); with `window` = (i_lo, i_hi, j_lo, j_hi) also returns sum r^2 over it (device tensor)."""
+        w = window or (0, 0, 0, 0)
+        _lib.check(self.lib.mg_dev_up_leg(sm, self.dt, self.dt, self.comp_dt, lnx, lny, u.stride(0), lnxc, lnyc, e_c.stride(0),
+                                          ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, self._p(u), self._p(rhs),
+                                          self._p(out), self._p(e_c), int(window is not None), w[0], w[1], w[2], w[3],
+                                          self._p(self.scratch), self._p(self.acc), self._stream()))
+        return self.acc.clone() if window is not None else None
+
+    def inject_ring(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides, ci_off, cj_off):
+        _lib.check(self.lib.mg_dev_inject_ring(self.dt, self.dt, lnxf, lnyf, fine.stride(0), lnxc, lnyc, coarse.stride(0), sides,
+                                               ci_off, cj_off, self._p(fine), self._p(coarse), self._stream()))
+
     # replicated coarse hierarchy = the single-GPU engine on this GPU, queued on the same stream
     def coarse_setup(self, NX, NY, domain, cfg):
         from .engine import MultigridEngine
@@ -198,6 +239,9 @@ class _Dom:
     """Per-rank state: one Block per distributed level and its fields."""
 
 
+GHOST_FUSED = 7      # smallest odd ghost width for which owned cells stay exact through a fused V(2,2) visit (Jacobi)
+
+
 class DistributedMultigrid:
     """V/W/F-cycle on a px x py block decomposition.
 
@@ -205,11 +249,14 @@ class DistributedMultigrid:
             in-process virtual-rank mode used by the single-GPU test).
     ops:    kernel provider (HipOps, or the tests' NumPy stand-in).
     dist:   torch.distributed module (initialised) or None for the in-process mode.
+    mode:   "fused" (ghost zone of 7 cells, two fused launches and ~one exchange per level; weighted Jacobi with
+            pre, post <= 2) or "per_operator" (1-cell ghost ring, one launch and one exchange per operator; any
+            smoother / sweep count).  "auto" picks "fused" whenever it applies.
     """
 
     def __init__(self, NX, NY, px, py, ranks, ops, dist=None, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0,
                  max_levels=None, cycle="V", pre=2, post=2, smoother="jacobi", omega=0.8, coarse_tol=1e-12,
-                 coarse_maxit=1000, agglomerate_at=1025):
+                 coarse_maxit=1000, agglomerate_at=1025, mode="auto"):
         from .facade import default_max_levels
         self.NX, self.NY, self.px, self.py = NX, NY, px, py
         self.ops, self.dist = ops, dist
@@ -218,43 +265,52 @@ class DistributedMultigrid:
         self.cycle_type, self.pre, self.post = cycle, pre, post
         if smoother not in ("jacobi", "rbgs"):
             raise ValueError(f"Unknown smoother: {smoother}")
+        if mode not in ("auto", "fused", "per_operator"):
+            raise ValueError(f"Unknown mode: {mode}")
+        can_fuse = smoother == "jacobi" and pre <= 2 and post <= 2 and hasattr(ops, "down_leg")
+        if mode == "fused" and not can_fuse:
+            raise ValueError("mode 'fused' needs weighted Jacobi with pre, post <= 2")
+        self.mode = "fused" if (mode in ("auto", "fused") and can_fuse) else "per_operator"
+        self.G = GHOST_FUSED if self.mode == "fused" else 1
         self.smoother, self.omega = smoother, omega
+        self.smk = _lib.MG_JACOBI if smoother == "jacobi" else _lib.MG_RBGS
         self.shapes = hierarchy_shapes(NX, NY, max_levels or default_max_levels(NX, NY))
         self.L = len(self.shapes)
-        self.Ld = distributed_levels(self.shapes, px, py, agglomerate_at) if px * py > 1 else 0
+        self.Ld = distributed_levels(self.shapes, px, py, agglomerate_at, self.G) if px * py > 1 else 0
         self.h = [((domain[1] - domain[0]) / (a - 1), (domain[3] - domain[2]) / (b - 1)) for a, b in self.shapes]
         self.ranks = list(ranks)
         self.doms = {}
+        self.exchanges = 0                      # halo exchanges issued (statistics)
         for r in self.ranks:
             rx, ry = divmod(r, py)
             d = _Dom()
             d.rank, d.rx, d.ry = r, rx, ry
-            d.blk = [Block(a, b, px, py, rx, ry) for (a, b) in self.shapes[:self.Ld + 1]]
+            d.blk = [Block(a, b, px, py, rx, ry, self.G) for (a, b) in self.shapes[:self.Ld + 1]]
             d.u, d.t, d.rhs, d.r = [], [], [], []
             for l in range(self.Ld):
                 b = d.blk[l]
                 d.u.append(ops.alloc(b.lnx, b.lny))
-                d.t.append(ops.alloc(b.lnx, b.lny) if smoother == "jacobi" else None)
+                d.t.append(ops.alloc(b.lnx, b.lny) if (smoother == "jacobi" or self.mode == "fused") else None)
                 d.rhs.append(ops.alloc(b.lnx, b.lny))
-                d.r.append(ops.alloc(b.lnx, b.lny))
+                d.r.append(ops.alloc(b.lnx, b.lny) if self.mode == "per_operator" else None)
             # the agglomeration level: a local coarse buffer (restriction target / prolongation source)
-            # and the replicated global arrays
             if self.Ld > 0:
                 b = d.blk[self.Ld]
-                d.rc = ops.alloc(b.lnx, b.lny)
+                d.rc = ops.alloc(b.lnx, b.lny)        # restricted rhs (its boundary ring is written once per rhs in fused mode)
+                d.ec = ops.alloc(b.lnx, b.lny)        # this rank's piece of the replicated correction
+            d.ring_sumsq = None
             self.doms[r] = d
         NXa, NYa = self.shapes[self.Ld]
         self.rhs_a = ops.alloc(NXa, NYa)
         self.e_a = ops.alloc(NXa, NYa)
-        smk = _lib.MG_JACOBI if smoother == "jacobi" else _lib.MG_RBGS
         ops.coarse_setup(NXa, NYa, domain, dict(coeff=coeff, levels=self.L - self.Ld, cycle=cycle, pre=pre, post=post,
-                                                smoother=smk, omega=omega, coarse_tol=coarse_tol, coarse_maxit=coarse_maxit))
+                                                smoother=self.smk, omega=omega, coarse_tol=coarse_tol, coarse_maxit=coarse_maxit))
         # gather buffers: exclusive blocks padded to the largest block
         if self.Ld > 0:
-            b0 = Block(NXa, NYa, px, py, 0, 0)
-            self.gmx = max(Block(NXa, NYa, px, py, rx, 0).i_hi - Block(NXa, NYa, px, py, rx, 0).i_lo for rx in range(px))
-            self.gmy = max(Block(NXa, NYa, px, py, 0, ry).j_hi - Block(NXa, NYa, px, py, 0, ry).j_lo for ry in range(py))
-            del b0
+            blocks = [Block(NXa, NYa, px, py, rx, ry, self.G) for rx in range(px) for ry in range(py)]
+            self.gmx = max(b.i_hi - b.i_lo for b in blocks)
+            self.gmy = max(b.j_hi - b.j_lo for b in blocks)
+        self._last_norm_parts = None
 
     # ---- neighbours ----------------------------------------------------------------------
     def _nbr(self, d, dx, dy):
@@ -264,8 +320,7 @@ class DistributedMultigrid:
         return None
 
     def _p2p(self, sends, recvs):
-        """sends/recvs: lists of (peer_rank, tensor).  Local peers are copied, remote ones go through
-        batched isend/irecv (RCCL send/recv, one group per phase)."""
+        """sends/recvs: lists of (peer_rank, tensor): batched isend/irecv (RCCL send/recv, one group per phase)."""
         if self.dist is None or not (sends or recvs):
             return
         ops = [self.dist.P2POp(self.dist.isend, t, p) for p, t in sends] + \
@@ -274,24 +329,30 @@ class DistributedMultigrid:
             req.wait()
 
     def exchange(self, name, l, corners=False):
-        """Fill the ghost ring of field `name` on level l from the neighbours' owned edges.
-        Rows first, then columns over the full (ring-inclusive) height, so corners arrive too."""
+        """Fill the ghost zone (G cells wide) of field `name` on level l from the neighbours' owned cells next to the
+        cut.  Rows first (whole rows: contiguous memory, no packing), then columns over the full local height, so the
+        corners arrive too."""
         torch = self.torch
+        G = self.G
+        self.exchanges += 1
         fields = {r: (getattr(d, name)[l] if isinstance(getattr(d, name), list) else getattr(d, name)) for r, d in self.doms.items()}
-        # phase 1: rows (contiguous in memory: no packing)
+        # phase 1: rows
         sends, recvs, local = [], [], []
         for r, d in self.doms.items():
             b, t = d.blk[l], fields[r]
-            for dx, src_row, dst_row in ((-1, 1, 0), (+1, b.lnx - 2, b.lnx - 1)):
+            for dx in (-1, +1):
                 p = self._nbr(d, dx, 0)
                 if p is None:
                     continue
-                if p in self.doms:       # neighbour lives in this process: read its owned edge directly
+                src = slice(b.oi_lo, b.oi_lo + G) if dx < 0 else slice(b.oi_hi - G + 1, b.oi_hi + 1)
+                dst = slice(b.oi_lo - G, b.oi_lo) if dx < 0 else slice(b.oi_hi + 1, b.oi_hi + 1 + G)
+                if p in self.doms:       # neighbour lives in this process: read its owned rows directly
                     pb = self.doms[p].blk[l]
-                    local.append((t[dst_row, :b.lny], fields[p][(pb.lnx - 2) if dx < 0 else 1, :pb.lny]))
+                    psrc = slice(pb.oi_hi - G + 1, pb.oi_hi + 1) if dx < 0 else slice(pb.oi_lo, pb.oi_lo + G)
+                    local.append((t[dst, :b.lny], fields[p][psrc, :pb.lny]))
                 else:
-                    sends.append((p, t[src_row, :b.lny]))
-                    recvs.append((p, t[dst_row, :b.lny]))
+                    sends.append((p, t[src]))          # whole padded rows: one contiguous chunk
+                    recvs.append((p, t[dst]))
         for dst, src in local:
             dst.copy_(src)
         self._p2p(sends, recvs)
@@ -299,19 +360,22 @@ class DistributedMultigrid:
         sends, recvs, local, unpack = [], [], [], []
         for r, d in self.doms.items():
             b, t = d.blk[l], fields[r]
-            for dy, src_col, dst_col in ((-1, 1, 0), (+1, b.lny - 2, b.lny - 1)):
+            for dy in (-1, +1):
                 p = self._nbr(d, 0, dy)
                 if p is None:
                     continue
+                src = slice(b.oj_lo, b.oj_lo + G) if dy < 0 else slice(b.oj_hi - G + 1, b.oj_hi + 1)
+                dst = slice(b.oj_lo - G, b.oj_lo) if dy < 0 else slice(b.oj_hi + 1, b.oj_hi + 1 + G)
                 if p in self.doms:
                     pb = self.doms[p].blk[l]
-                    local.append((t[:b.lnx, dst_col], fields[p][:pb.lnx, (pb.lny - 2) if dy < 0 else 1]))
+                    psrc = slice(pb.oj_hi - G + 1, pb.oj_hi + 1) if dy < 0 else slice(pb.oj_lo, pb.oj_lo + G)
+                    local.append((t[:b.lnx, dst], fields[p][:pb.lnx, psrc]))
                 else:
-                    sbuf = t[:b.lnx, src_col].contiguous()
+                    sbuf = t[:b.lnx, src].contiguous()
                     rbuf = torch.empty_like(sbuf)
                     sends.append((p, sbuf))
                     recvs.append((p, rbuf))
-                    unpack.append((t[:b.lnx, dst_col], rbuf))
+                    unpack.append((t[:b.lnx, dst], rbuf))
         for dst, src in local:
             dst.copy_(src)
         self._p2p(sends, recvs)
@@ -345,9 +409,21 @@ class DistributedMultigrid:
         parts = [torch.empty_like(mine) for _ in range(self.px * self.py)]
         self.dist.all_gather(parts, mine)
         for q, part in enumerate(parts):
-            qb = Block(NXa, NYa, self.px, self.py, *divmod(q, self.py))
+            qb = Block(NXa, NYa, self.px, self.py, *divmod(q, self.py), self.G)
             self.rhs_a[qb.gx0 + qb.i_lo:qb.gx0 + qb.i_hi, qb.gy0 + qb.j_lo:qb.gy0 + qb.j_hi] = \
                 part[:qb.i_hi - qb.i_lo, :qb.j_hi - qb.j_lo]
+
+    def _replicated_cycle(self, l):
+        """Coarse tail: gather the coarse rhs, run the remaining levels on the single-GPU engine (on every GPU),
+        take this rank's piece of the correction (ghost zone included: it is global data)."""
+        self._gather_coarse_rhs()
+        self.ops.coarse_begin(self.rhs_a)
+        for _ in range(self._reps(l)):
+            self.ops.coarse_cycle()
+        self.ops.coarse_end(self.e_a)
+        for d in self.doms.values():
+            bc = d.blk[l + 1]
+            d.ec[:bc.lnx, :bc.lny] = self.e_a[bc.gx0:bc.gx0 + bc.lnx, bc.gy0:bc.gy0 + bc.lny]
 
     # ---- the cycle (solvers/multigrid.py:253-337) ------------------------------------------------
     def _reps(self, l):
@@ -374,9 +450,53 @@ class DistributedMultigrid:
                                              (b.gx0 + b.gy0) & 1)
                     self.exchange("u", l)
 
-    def cycle(self, l=0):
+    def cycle(self, l=0, zero_u=False):
         if self.Ld == 0:                      # nothing distributed: the replicated engine is the whole solver
             raise RuntimeError("single-block problems go through MultigridEngine")
+        self._last_norm_parts = None
+        if self.mode == "fused":
+            return self._cycle_fused(l, zero_u)
+        return self._cycle_per_operator(l)
+
+    def _cycle_fused(self, l, zero_u):
+        """Two launches and (at most) two exchanges per level.  Validity bookkeeping (m = cells of the ghost zone that
+        are exact, counted from the owned cells outwards; G = 7): after an exchange m = 7; the down leg's two sweeps
+        leave the iterate exact on m = 5, its restriction is exact on all owned coarse cells; the correction that
+        comes back from below is exact on m_c >= 3 coarse cells = 6 fine cells, so after the up leg (prolongation,
+        two sweeps) m = min(5, 6) - 2 = 3 >= 0, and the norm (one more cell) only reads exact values."""
+        hx, hy = self.h[l]
+        last = (l + 1 == self.Ld)
+        if not zero_u:
+            self.exchange("u", l)                        # level 0 every cycle; coarser levels only when re-visited (W, F)
+        for d in self.doms.values():
+            b, bc = d.blk[l], d.blk[l + 1]
+            ci, cj = b.coarse_offsets(bc)
+            target = d.rc if last else d.rhs[l + 1]
+            self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l], target, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, hx, hy,
+                              self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1)
+            d.u[l], d.t[l] = d.t[l], d.u[l]
+        if last:
+            self._replicated_cycle(l)
+        else:
+            self.exchange("rhs", l + 1)                  # owned coarse rhs -> the neighbours' ghost zones
+            for k in range(self._reps(l)):
+                self._cycle_fused(l + 1, k == 0)
+        want_norm = (l == 0)
+        parts = {}
+        for r, d in self.doms.items():
+            b, bc = d.blk[l], d.blk[l + 1]
+            ci, cj = b.coarse_offsets(bc)
+            e = d.ec if last else d.u[l + 1]
+            win = (max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), max(b.j_lo, 1), min(b.j_hi, b.lny - 1)) if want_norm else None
+            res = self.ops.up_leg(self.smk, d.u[l], d.rhs[l], d.t[l], e, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides, hx, hy,
+                                  self.omega, self.coeff, self.post, (b.gx0 + b.gy0) & 1, win)
+            d.u[l], d.t[l] = d.t[l], d.u[l]
+            if want_norm:
+                parts[r] = res + d.ring_sumsq
+        if want_norm:
+            self._last_norm_parts = parts
+
+    def _cycle_per_operator(self, l):
         hx, hy = self.h[l]
         if self.pre > 0:
             self.smooth(l, self.pre)
@@ -390,20 +510,15 @@ class DistributedMultigrid:
             target = d.rc if last else d.rhs[l + 1]
             self.ops.restrict(d.r[l], target, b.lnx, b.lny, bc.lnx, bc.lny, bc.sides)
         if last:
-            self._gather_coarse_rhs()
-            self.ops.coarse_begin(self.rhs_a)
-            for _ in range(self._reps(l)):
-                self.ops.coarse_cycle()
-            self.ops.coarse_end(self.e_a)
+            self._replicated_cycle(l)
             for d in self.doms.values():
                 b, bc = d.blk[l], d.blk[l + 1]
-                d.rc[:bc.lnx, :bc.lny] = self.e_a[bc.gx0:bc.gx0 + bc.lnx, bc.gy0:bc.gy0 + bc.lny]
-                self.ops.prolong_add(d.rc, d.u[l], b.lnx, b.lny, bc.lnx, bc.lny, b.sides)
+                self.ops.prolong_add(d.ec, d.u[l], b.lnx, b.lny, bc.lnx, bc.lny, b.sides)
         else:
             for d in self.doms.values():
                 d.u[l + 1].zero_()
             for _ in range(self._reps(l)):
-                self.cycle(l + 1)
+                self._cycle_per_operator(l + 1)
             for d in self.doms.values():
                 b, bc = d.blk[l], d.blk[l + 1]
                 self.ops.prolong_add(d.u[l + 1], d.u[l], b.lnx, b.lny, bc.lnx, bc.lny, b.sides)
@@ -412,7 +527,7 @@ class DistributedMultigrid:
 
     # ---- fields in / out -------------------------------------------------------------------------
     def set_problem(self, rhs_of_block, u0_of_block=None):
-        """rhs_of_block(block) -> (lnx, lny) array of f on that block (ring included)."""
+        """rhs_of_block(block) -> (lnx, lny) array of f on that block (ghost zone and boundary included)."""
         torch = self.torch
         for d in self.doms.values():
             b = d.blk[0]
@@ -422,14 +537,40 @@ class DistributedMultigrid:
                 d.u[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(u0_of_block(b), dtype=self.ops.np_dtype)).to(d.u[0].device)
             if d.t[0] is not None:
                 d.t[0].copy_(d.u[0])
+            if self.mode == "fused":
+                # boundary ring of every coarse rhs = injected ring of f (r = f on boundary cells), once per rhs;
+                # sum of f^2 over the physical boundary cells of the exclusive window, for the norm
+                for l in range(self.Ld):
+                    bf, bc = d.blk[l], d.blk[l + 1]
+                    ci, cj = bf.coarse_offsets(bc)
+                    target = d.rc if l + 1 == self.Ld else d.rhs[l + 1]
+                    self.ops.inject_ring(d.rhs[l], target, bf.lnx, bf.lny, bc.lnx, bc.lny, bf.sides, ci, cj)
+                ring = torch.zeros(1, dtype=torch.float64, device=d.rhs[0].device)
+                if b.sides & SIDE_ILO:
+                    ring = ring + self.ops.sumsq(d.rhs[0], 0, 1, b.j_lo, b.j_hi)
+                if b.sides & SIDE_IHI:
+                    ring = ring + self.ops.sumsq(d.rhs[0], b.lnx - 1, b.lnx, b.j_lo, b.j_hi)
+                if b.sides & SIDE_JLO:
+                    ring = ring + self.ops.sumsq(d.rhs[0], max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), 0, 1)
+                if b.sides & SIDE_JHI:
+                    ring = ring + self.ops.sumsq(d.rhs[0], max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), b.lny - 1, b.lny)
+                d.ring_sumsq = ring
+        self._last_norm_parts = None
 
     def residual_norm(self):
         hx, hy = self.h[0]
+        if self._last_norm_parts is not None:       # the up leg of the last cycle already summed r^2 over the owned cells
+            return math.sqrt(hx * hy * self.allreduce_sum(self._last_norm_parts))
+        if self.mode == "fused":
+            self.exchange("u", 0)
         parts = {}
         for r, d in self.doms.items():
             b = d.blk[0]
-            self.ops.residual(d.u[0], d.rhs[0], d.r[0], b.lnx, b.lny, hx, hy, self.coeff)
-            parts[r] = self.ops.sumsq(d.r[0], b.i_lo, b.i_hi, b.j_lo, b.j_hi)
+            tmp = d.r[0] if d.r[0] is not None else d.t[0]
+            self.ops.residual(d.u[0], d.rhs[0], tmp, b.lnx, b.lny, hx, hy, self.coeff)
+            parts[r] = self.ops.sumsq(tmp, b.i_lo, b.i_hi, b.j_lo, b.j_hi)
+            if d.r[0] is None:                       # t doubled as scratch: restore its boundary ring / contents
+                tmp.copy_(d.u[0])
         return math.sqrt(hx * hy * self.allreduce_sum(parts))
 
     def local_solution(self, rank):

@@ -78,6 +78,64 @@ class NumpyOps:
             P = np.where((io == 0) & (jo == 1) & (i == lnxf - 1), 0.0, P)
         u[valid] = (u + P.astype(u.dtype))[valid]
 
+    # ---- fused legs with sub-domain semantics (every edge of the local array is treated as fixed) ----------------
+    def _prolong_field(self, e, lnxf, lnyf, lnxc, lnyc, ci_off, cj_off, sides, dtype):
+        i = np.arange(lnxf)[:, None]; j = np.arange(lnyf)[None, :]
+        ic, io, jc, jo = (i >> 1) + ci_off, i & 1, (j >> 1) + cj_off, j & 1
+        valid = (ic >= 0) & (jc >= 0) & (ic + io < lnxc) & (jc + jo < lnyc)
+        icc, jcc = np.clip(ic, 0, lnxc - 1), np.clip(jc, 0, lnyc - 1)
+        ic1, jc1 = np.clip(ic + 1, 0, lnxc - 1), np.clip(jc + 1, 0, lnyc - 1)
+        e00, e01, e10, e11 = e[icc, jcc], e[icc, jc1], e[ic1, jcc], e[ic1, jc1]
+        P = np.where((io == 0) & (jo == 0), e00,
+            np.where((io == 1) & (jo == 0), 0.5 * (e00 + e10),
+            np.where((io == 0) & (jo == 1), 0.5 * (e00 + e01), 0.25 * (((e00 + e01) + e10) + e11))))
+        if sides & SIDE_JHI:
+            P = np.where((io == 1) & (jo == 0) & (j == lnyf - 1), 0.0, P)
+        if sides & SIDE_IHI:
+            P = np.where((io == 0) & (jo == 1) & (i == lnxf - 1), 0.0, P)
+        return P.astype(dtype), valid
+
+    def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff):
+        f = self._v(rhs, lnx, lny)
+        v = np.zeros_like(f) if zero_init else self._v(u, lnx, lny).copy()
+        v = O.jacobi(v, f, hx, hy, omega, nsweep, "vectorized")
+        self._v(out, lnx, lny)[1:, :] = v[1:, :]                    # the kernel never writes row 0
+        r = O.residual(v, f, hx, hy, coeff)
+        c = self._v(rhs_c, lnxc, lnyc)
+        ic = np.arange(1, lnxc - 1); jc = np.arange(1, lnyc - 1)
+        fi = 2 * (ic - ci_off); fj = 2 * (jc - cj_off)
+        oki = (fi >= 1) & (fi <= lnx - 2); okj = (fj >= 1) & (fj <= lny - 2)
+        I, J = np.meshgrid(fi[oki], fj[okj], indexing="ij")
+        corners = ((r[I - 1, J - 1] + r[I - 1, J + 1]) + r[I + 1, J - 1]) + r[I + 1, J + 1]
+        edges = ((r[I - 1, J] + r[I + 1, J]) + r[I, J - 1]) + r[I, J + 1]
+        c[np.ix_(ic[oki], jc[okj])] = (1.0 / 16.0 * corners + 1.0 / 8.0 * edges) + 1.0 / 4.0 * r[I, J]
+
+    def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, window=None):
+        f = self._v(rhs, lnx, lny)
+        v = self._v(u, lnx, lny).copy()
+        P, valid = self._prolong_field(self._v(e_c, lnxc, lnyc), lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, v.dtype)
+        v[valid] = (v + P)[valid]
+        v = O.jacobi(v, f, hx, hy, omega, nsweep, "vectorized")
+        self._v(out, lnx, lny)[1:, :] = v[1:, :]
+        if window is None:
+            return None
+        r = O.residual(v, f, hx, hy, coeff)
+        i_lo, i_hi, j_lo, j_hi = window
+        w = r[max(i_lo, 1):min(i_hi, lnx - 1), max(j_lo, 1):min(j_hi, lny - 1)].astype(np.float64)
+        return torch.tensor([float(np.sum(w * w))], dtype=torch.float64)
+
+    def inject_ring(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides, ci_off, cj_off):
+        f, c = self._v(fine, lnxf, lnyf), self._v(coarse, lnxc, lnyc)
+        for side, rows, cols in ((SIDE_ILO, [0], range(lnyc)), (SIDE_IHI, [lnxc - 1], range(lnyc)),
+                                 (SIDE_JLO, range(lnxc), [0]), (SIDE_JHI, range(lnxc), [lnyc - 1])):
+            if not sides & side:
+                continue
+            for a in rows:
+                for b in cols:
+                    fi, fj = 2 * (a - ci_off), 2 * (b - cj_off)
+                    if 0 <= fi < lnxf and 0 <= fj < lnyf:
+                        c[a, b] = f[fi, fj]
+
     # replicated coarse hierarchy: the oracle's single-domain cycle
     def coarse_setup(self, NX, NY, domain, cfg):
         kind = {0: "jacobi", 1: "rbgs"}[cfg["smoother"]]

@@ -62,10 +62,10 @@ def _u0(NX, NY):
     return rng.standard_normal((NX, NY))                                           # non-zero Dirichlet data + guess
 
 
-def _run_ranks(NX, NY, px, py, ranks, dist, levels, cyc, kind, omega, ncycles, agg, domain=(0.0, 1.0, 0.0, 1.0)):
+def _run_ranks(NX, NY, px, py, ranks, dist, levels, cyc, kind, omega, ncycles, agg, domain=(0.0, 1.0, 0.0, 1.0), mode="per_operator"):
     rhs, u0 = _rhs(NX, NY, domain), _u0(NX, NY)
     s = D.DistributedMultigrid(NX, NY, px, py, ranks, H.NumpyOps(), dist, domain=domain, max_levels=levels, cycle=cyc,
-                               smoother=kind, omega=omega, agglomerate_at=agg, coarse_maxit=40)   # rhs has boundary noise: the
+                               smoother=kind, omega=omega, agglomerate_at=agg, coarse_maxit=40, mode=mode)   # rhs has boundary noise: the
     # coarsest solve never meets its tolerance and would burn 1000 sweeps per visit
     s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny],
                   lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
@@ -87,6 +87,32 @@ def test_virtual_ranks_equal_single_domain(px, py, cyc, kind, omega):
     np.testing.assert_allclose(hist, h_ref, rtol=1e-13)
 
 
+@pytest.mark.parametrize("px,py,NX,NY,agg", [(2, 1, 129, 65, 33), (1, 2, 65, 129, 33), (2, 2, 129, 129, 33), (4, 2, 257, 129, 33), (2, 2, 129, 129, 65)])
+@pytest.mark.parametrize("cyc,omega", [("V", 0.8), ("W", 0.8), ("F", 2 / 3)])
+def test_fused_mode_virtual_ranks_equal_single_domain(px, py, NX, NY, agg, cyc, omega):
+    """Communication-avoiding mode: ghost zones of 7 cells, fused legs, one exchange of the iterate per cycle and one
+    of each coarse rhs.  Owned cells must still equal the single-domain oracle bit for bit, and the norm the up leg
+    accumulates must be the global residual norm."""
+    levels = D.hierarchy_shapes(NX, NY, 99).__len__()
+    u_ref, h_ref = _oracle(NX, NY, levels, cyc, "jacobi", omega, 3)
+    s, hist = _run_ranks(NX, NY, px, py, range(px * py), None, levels, cyc, "jacobi", omega, 3, agg=agg, mode="fused")
+    assert s.mode == "fused" and s.G == 7 and s.Ld >= 1
+    np.testing.assert_array_equal(H.assemble(s, NX, NY), u_ref)
+    np.testing.assert_allclose(hist, h_ref, rtol=1e-13)
+    if cyc == "V":
+        assert s.exchanges == 3 * (1 + (s.Ld - 1))          # per cycle: the fine iterate + one per distributed coarse rhs
+
+
+def test_fused_mode_block_bookkeeping():
+    b0, b1 = D.Block(8193, 4097, 2, 1, 0, 0, 7), D.Block(8193, 4097, 2, 1, 1, 0, 7)
+    assert (b0.gx0, b0.lnx, b0.oi_lo, b0.oi_hi) == (0, 4097 + 7, 1, 4096)          # rows 0 .. 4096+7
+    assert (b1.gx0, b1.lnx, b1.oi_lo, b1.oi_hi) == (4096 - 6, 4097 + 6, 7, 7 + 4094)   # rows 4090 .. 8192
+    c1 = D.Block(4097, 2049, 2, 1, 1, 0, 7)
+    assert b1.coarse_offsets(c1) == (3, 0) and b0.coarse_offsets(D.Block(4097, 2049, 2, 1, 0, 0, 7)) == (0, 0)
+    assert b1.gx0 % 2 == 0 and c1.gx0 % 2 == 0
+    assert D.distributed_levels(D.hierarchy_shapes(8193, 8193, 12), 2, 2, 1025, 7) == 3
+
+
 def test_virtual_ranks_rectangular_cells_and_single_distributed_level():
     dom = (0.0, 2.0, 0.0, 1.0)
     u_ref, h_ref = _oracle(129, 33, 4, "V", "jacobi", 0.8, 2, dom)
@@ -103,14 +129,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, px, py, cyc, kind, omega, out_path):
+def _worker(rank, world, port, px, py, cyc, kind, omega, out_path, mode="per_operator"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    NX = NY = 65
-    s, hist = _run_ranks(NX, NY, px, py, [rank], dist, 4, cyc, kind, omega, 3, agg=17)
+    NX = NY = 65 if mode == "per_operator" else 129
+    s, hist = _run_ranks(NX, NY, px, py, [rank], dist, 4 if mode == "per_operator" else 5, cyc, kind, omega, 3,
+                         agg=17 if mode == "per_operator" else 33, mode=mode)
     b, u = s.local_solution(rank)
     gathered = [None] * world
     dist.all_gather_object(gathered, (b.gx0, b.gy0, b.i_lo, b.i_hi, b.j_lo, b.j_hi, u))
@@ -131,5 +158,17 @@ def test_gloo_multiprocess_equals_single_domain(tmp_path, world, cyc, kind, omeg
     mp.spawn(_worker, args=(world, _free_port(), px, py, cyc, kind, omega, out), nprocs=world, join=True)
     res = np.load(out)
     u_ref, h_ref = _oracle(65, 65, 4, cyc, kind, omega, 3)
+    np.testing.assert_array_equal(res["u"], u_ref)
+    np.testing.assert_allclose(res["hist"], h_ref, rtol=1e-13)
+
+
+@pytest.mark.parametrize("world,cyc", [(2, "V"), (4, "V"), (4, "W")])
+def test_gloo_multiprocess_fused_mode(tmp_path, world, cyc):
+    import torch.multiprocessing as mp
+    px, py = D.process_grid(world)
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), px, py, cyc, "jacobi", 0.8, out, "fused"), nprocs=world, join=True)
+    res = np.load(out)
+    u_ref, h_ref = _oracle(129, 129, 5, cyc, "jacobi", 0.8, 3)
     np.testing.assert_array_equal(res["u"], u_ref)
     np.testing.assert_allclose(res["hist"], h_ref, rtol=1e-13)

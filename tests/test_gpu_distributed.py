@@ -20,8 +20,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32, "managed32"])
 @pytest.mark.parametrize("px,py,NX,NY,agg", [(2, 1, 513, 257, 65), (2, 2, 513, 513, 129), (4, 2, 1025, 513, 129), (1, 2, 257, 1025, 33)])
-@pytest.mark.parametrize("cyc,kind,omega", [("V", "jacobi", 0.8), ("W", "rbgs", 1.0)])
-def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cyc, kind, omega):
+@pytest.mark.parametrize("cyc,kind,omega,mode", [("V", "jacobi", 0.8, "per_operator"), ("W", "rbgs", 1.0, "per_operator"),
+                                                 ("V", "jacobi", 0.8, "fused"), ("W", "jacobi", 0.8, "fused")])
+def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cyc, kind, omega, mode):
     import torch
     managed = dtype == "managed32"
     dtype = np.float32 if managed else dtype
@@ -42,8 +43,8 @@ def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cy
 
     ops = D.HipOps(dtype, torch.device("cuda", 0), managed_single=managed)
     s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle=cyc, smoother=kind,
-                               omega=omega, agglomerate_at=agg)
-    assert s.Ld >= 2
+                               omega=omega, agglomerate_at=agg, mode=mode)
+    assert s.Ld >= 2 and s.mode == mode
     s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
     hist = []
     for _ in range(ncyc):
