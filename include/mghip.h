@@ -209,12 +209,14 @@ int mg_dev_convert(int in_dtype, int out_dtype, int nx, int ny, int ldi, int ldo
  * of a ghost zone are stale -- the caller sizes the zone so that the cells it owns stay exact.  Coarse cell (ic, jc)
  * sits on fine cell (2 (ic - ci_off), 2 (jc - cj_off)).
  *   down leg: nsweep (<= 2) sweeps of u (or of the zero iterate: zero_init) -> out; residual; full weighting into the
- *             interior cells of rhs_coarse that have a complete fine neighbourhood here.
+ *             interior cells of rhs_coarse that have a complete fine neighbourhood here.  `select` = 0 runs every tile;
+ *             1 only the tiles whose staged region lies inside inner_rect = {i_lo, i_hi, j_lo, j_hi} (cells that need no
+ *             ghost data: launch them while the halo exchange is in flight), 2 only the remaining tiles.
  *   up leg:   out = sweeps(u + P e_coarse); with norm != 0 also *sumsq_dev = sum of r^2 over cells
  *             [ni_lo, ni_hi) x [nj_lo, nj_hi) that are interior to this array (scratch >= mg_dev_scratch_bytes()). */
 int mg_dev_down_leg(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
                     int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
-                    const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream);
+                    const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream, int select, const int* inner_rect);
 int mg_dev_up_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
                   int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
                   const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,

@@ -90,7 +90,7 @@ SIGNATURES = {
     "mg_zero_solution_device": (_i, [_vp]),
     "mg_get_solution_device": (_i, [_vp, _vp, _i, _i]),
     "mg_dev_convert": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "mg_dev_down_leg": (_i, [_i] * 11 + [_d] * 4 + [_i] * 3 + [_vp] * 5),
+    "mg_dev_down_leg": (_i, [_i] * 11 + [_d] * 4 + [_i] * 3 + [_vp] * 5 + [_i, C.POINTER(C.c_int)]),
     "mg_dev_up_leg": (_i, [_i] * 13 + [_d] * 4 + [_i] * 2 + [_vp] * 4 + [_i] * 5 + [_vp] * 3),
     "mg_dev_inject_ring": (_i, [_i] * 11 + [_vp] * 3),
     "mg_dev_scratch_bytes": (_i, [_i, _i, C.POINTER(C.c_int64)]),

@@ -1131,6 +1131,9 @@ struct FusedArgs {
   int ci_off, cj_off;           // coarse (ic, jc) <-> fine (2 (ic - ci_off), 2 (jc - cj_off)); 0 for whole grids
   int sides;                    // physical-boundary edges of this array (far-edge rule of the prolongation)
   int ni_lo, ni_hi, nj_lo, nj_hi;   // cells counted by the norm stage (whole grid: the interior)
+  // tile selection (overlap of a halo exchange with the tiles that do not need it): 0 all tiles, 1 only tiles whose
+  // staged region lies inside [in_i_lo, in_i_hi) x [in_j_lo, in_j_hi), 2 only the others
+  int select, in_i_lo, in_i_hi, in_j_lo, in_j_hi;
 };
 
 template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM>
@@ -1150,6 +1153,13 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   const int ti = L / a.tiles_j, tj = L - ti * a.tiles_j;
   const int i0 = 1 + ti * kFusedTI, j0 = tj * S::TJ;
   const int ri0 = i0 - HALO, rj0 = j0 - S::HV * N;           // global coords of region cell (0,0)
+  if (a.select != 0) {
+    const bool inner = ri0 >= a.in_i_lo && ri0 + S::RI <= a.in_i_hi && rj0 >= a.in_j_lo && rj0 + S::RJ <= a.in_j_hi;
+    if ((a.select == 1) != inner) {
+      if (POST == kPostNorm && threadIdx.x == 0) partials[blockIdx.x] = 0.0;
+      return;
+    }
+  }
   const int cv = threadIdx.x % S::VPR, rg = threadIdx.x / S::VPR;
   const bool worker = rg < S::RG;
   const int gj0 = rj0 + cv * N;

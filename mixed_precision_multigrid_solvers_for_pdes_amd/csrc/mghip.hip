@@ -298,6 +298,7 @@ mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int n
   a.nxc = nxc; a.nyc = nyc; a.ldc = ldc;
   a.ci_off = a.cj_off = 0; a.sides = mg::kAllSides;
   a.ni_lo = 1; a.ni_hi = nx - 1; a.nj_lo = 1; a.nj_hi = ny - 1;
+  a.select = 0; a.in_i_lo = a.in_j_lo = 0; a.in_i_hi = a.in_j_hi = 0;
   return a;
 }
 
@@ -309,10 +310,12 @@ struct LegGeom {      // what every fused launch needs
   // sub-domain extras (defaults = whole grid)
   int ci_off = 0, cj_off = 0, sides = mg::kAllSides;
   int ni_lo = -1, ni_hi = -1, nj_lo = -1, nj_hi = -1;     // norm window; -1: the interior
+  int select = 0, in_i_lo = 0, in_i_hi = 0, in_j_lo = 0, in_j_hi = 0;   // tile selection (see mg::FusedArgs)
 };
 inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
   a.ci_off = g.ci_off; a.cj_off = g.cj_off; a.sides = g.sides;
   if (g.ni_lo >= 0) { a.ni_lo = g.ni_lo; a.ni_hi = g.ni_hi; a.nj_lo = g.nj_lo; a.nj_hi = g.nj_hi; }
+  a.select = g.select; a.in_i_lo = g.in_i_lo; a.in_i_hi = g.in_i_hi; a.in_j_lo = g.in_j_lo; a.in_j_hi = g.in_j_hi;
 }
 
 // down leg: nsweep sweeps + residual + full-weighting restriction (interior coarse cells).  TX = coarse rhs dtype.
@@ -1560,12 +1563,14 @@ int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int 
 // ---- fused legs on device arrays (sub-domains: wide ghost zones, coarse offsets, norm window) --------------------
 int mg_dev_down_leg(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
                     int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
-                    const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream) {
+                    const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream, int select, const int* inner_rect) {
   CHECK_DEV((smoother == MG_JACOBI || smoother == MG_RBGS) && valid_dtype(dtype) && valid_dtype(coarse_dtype), "mg_dev_down_leg: bad smoother / dtype");
   CHECK_DEV(nx >= 3 && ny >= 3 && nxc >= 3 && nyc >= 3 && ld_ok(dtype, ny, ld) && ldc >= nyc && nsweep >= 0 && nsweep <= 2, "mg_dev_down_leg: bad shape / pitch / sweep count");
   CHECK_DEV(rhs && out && rhs_coarse && (zero_init || u) && u != out && aligned16(rhs) && aligned16(out) && (!u || aligned16(u)), "mg_dev_down_leg: bad pointer");
   LegGeom g{nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, colour_offset, false};
   g.ci_off = ci_off; g.cj_off = cj_off;
+  CHECK_DEV(select >= 0 && select <= 2 && (select == 0 || inner_rect), "mg_dev_down_leg: bad tile selection");
+  if (select) { g.select = select; g.in_i_lo = inner_rect[0]; g.in_i_hi = inner_rect[1]; g.in_j_lo = inner_rect[2]; g.in_j_hi = inner_rect[3]; }
   d_down(smoother, dtype, coarse_dtype, u ? u : rhs, rhs, out, rhs_coarse, g, zero_init != 0, (hipStream_t)stream);
   HIPC(nullptr, hipGetLastError());
   return MG_OK;

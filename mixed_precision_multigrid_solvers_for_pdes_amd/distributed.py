@@ -184,11 +184,16 @@ class HipOps:
                                                coarse.stride(0), sides, self._p(coarse), self._p(fine_u), self._stream()))
 
     # fused legs (mode "fused"): the single-GPU engine's kernels on the local array with its ghost zone
-    def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff):
+    supports_overlap = True
+
+    def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff,
+                 select=0, inner=None):
+        """select: 0 all tiles; 1 only tiles that need nothing outside `inner` = (i_lo, i_hi, j_lo, j_hi); 2 the others."""
+        rect = (C.c_int * 4)(*inner) if inner is not None else None
         _lib.check(self.lib.mg_dev_down_leg(sm, self.dt, self.dt, lnx, lny, rhs.stride(0), lnxc, lnyc, rhs_c.stride(0), ci_off,
                                             cj_off, hx, hy, omega, coeff, nsweep, int(zero_init), poff,
                                             None if zero_init else self._p(u), self._p(rhs), self._p(out), self._p(rhs_c),
-                                            self._stream()))
+                                            self._stream(), int(select), rect))
 
     def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff,
                window=None):
@@ -256,7 +261,7 @@ class DistributedMultigrid:
 
     def __init__(self, NX, NY, px, py, ranks, ops, dist=None, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0,
                  max_levels=None, cycle="V", pre=2, post=2, smoother="jacobi", omega=0.8, coarse_tol=1e-12,
-                 coarse_maxit=1000, agglomerate_at=1025, mode="auto"):
+                 coarse_maxit=1000, agglomerate_at=1025, mode="auto", overlap=True):
         from .facade import default_max_levels
         self.NX, self.NY, self.px, self.py = NX, NY, px, py
         self.ops, self.dist = ops, dist
@@ -311,6 +316,12 @@ class DistributedMultigrid:
             self.gmx = max(b.i_hi - b.i_lo for b in blocks)
             self.gmy = max(b.j_hi - b.j_lo for b in blocks)
         self._last_norm_parts = None
+        # exchange / compute overlap on a second stream (device kernels only)
+        self.overlap = bool(overlap) and self.mode == "fused" and getattr(ops, "supports_overlap", False)
+        if self.overlap:
+            torch = self.torch
+            self._comm_stream = torch.cuda.Stream()
+            self._ev_a, self._ev_b = torch.cuda.Event(), torch.cuda.Event()
 
     # ---- neighbours ----------------------------------------------------------------------
     def _nbr(self, d, dx, dy):
@@ -458,7 +469,7 @@ class DistributedMultigrid:
             return self._cycle_fused(l, zero_u)
         return self._cycle_per_operator(l)
 
-    def _cycle_fused(self, l, zero_u):
+    def _cycle_fused(self, l, zero_u, first_visit_rhs=False):
         """Two launches and (at most) two exchanges per level.  Validity bookkeeping (m = cells of the ghost zone that
         are exact, counted from the owned cells outwards; G = 7): after an exchange m = 7; the down leg's two sweeps
         leave the iterate exact on m = 5, its restriction is exact on all owned coarse cells; the correction that
@@ -466,21 +477,52 @@ class DistributedMultigrid:
         two sweeps) m = min(5, 6) - 2 = 3 >= 0, and the norm (one more cell) only reads exact values."""
         hx, hy = self.h[l]
         last = (l + 1 == self.Ld)
+        # What this level's down leg is waiting for: the iterate's ghost zone (level 0 every cycle; coarser levels only
+        # when re-visited by a W / F cycle) and, below level 0, the ghost zone of the rhs the level above just produced.
+        pending = []
         if not zero_u:
-            self.exchange("u", l)                        # level 0 every cycle; coarser levels only when re-visited (W, F)
+            pending.append("u")
+        if l > 0 and first_visit_rhs:
+            pending.append("rhs")
+
+        def down(select, inner_of):
+            for d in self.doms.values():
+                b, bc = d.blk[l], d.blk[l + 1]
+                ci, cj = b.coarse_offsets(bc)
+                target = d.rc if last else d.rhs[l + 1]
+                self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l], target, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, hx, hy,
+                                  self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1,
+                                  select, inner_of(b) if select else None)
+
+        def inner_rect(b):      # cells whose values do not come out of an exchange: owned cells and physical boundary
+            big = 1 << 30
+            return (-big if b.sides & SIDE_ILO else b.oi_lo, big if b.sides & SIDE_IHI else b.oi_hi + 1,
+                    -big if b.sides & SIDE_JLO else b.oj_lo, big if b.sides & SIDE_JHI else b.oj_hi + 1)
+
+        if pending and self.overlap:
+            # tiles that read no ghost data run on the compute stream while the exchange runs on the comm stream
+            torch = self.torch
+            compute = torch.cuda.current_stream()
+            self._ev_a.record(compute)
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(self._ev_a)
+                for name in pending:
+                    self.exchange(name, l)
+                self._ev_b.record(self._comm_stream)
+            down(1, inner_rect)
+            compute.wait_event(self._ev_b)
+            down(2, inner_rect)
+        else:
+            for name in pending:
+                self.exchange(name, l)
+            down(0, None)
         for d in self.doms.values():
-            b, bc = d.blk[l], d.blk[l + 1]
-            ci, cj = b.coarse_offsets(bc)
-            target = d.rc if last else d.rhs[l + 1]
-            self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l], target, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, hx, hy,
-                              self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1)
             d.u[l], d.t[l] = d.t[l], d.u[l]
         if last:
             self._replicated_cycle(l)
         else:
-            self.exchange("rhs", l + 1)                  # owned coarse rhs -> the neighbours' ghost zones
             for k in range(self._reps(l)):
-                self._cycle_fused(l + 1, k == 0)
+                self._cycle_fused(l + 1, k == 0, k == 0)
         want_norm = (l == 0)
         parts = {}
         for r, d in self.doms.items():

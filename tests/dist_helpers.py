@@ -95,7 +95,9 @@ class NumpyOps:
             P = np.where((io == 0) & (jo == 1) & (i == lnxf - 1), 0.0, P)
         return P.astype(dtype), valid
 
-    def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff):
+    def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff,
+                 select=0, inner=None):
+        assert select == 0          # no streams on the CPU: the driver never splits the launch here
         f = self._v(rhs, lnx, lny)
         v = np.zeros_like(f) if zero_init else self._v(u, lnx, lny).copy()
         v = O.jacobi(v, f, hx, hy, omega, nsweep, "vectorized")

@@ -43,8 +43,8 @@ def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cy
 
     ops = D.HipOps(dtype, torch.device("cuda", 0), managed_single=managed)
     s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle=cyc, smoother=kind,
-                               omega=omega, agglomerate_at=agg, mode=mode)
-    assert s.Ld >= 2 and s.mode == mode
+                               omega=omega, agglomerate_at=agg, mode=mode, overlap=(dtype != np.float64 or cyc == "V"))
+    assert s.Ld >= 2 and s.mode == mode and s.overlap == (mode == "fused" and (dtype != np.float64 or cyc == "V"))
     s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
     hist = []
     for _ in range(ncyc):
