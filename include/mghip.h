@@ -133,6 +133,14 @@ int mg_iterate(mg_handle* h, double tol, int max_iter, double* hist, int hist_ca
  * Cycles of a variable-coefficient handle run one launch per operator (the fused legs are constant-coefficient). */
 int mg_set_coefficient(mg_handle* h, const void* a_host_or_null, int host_dtype);
 
+/* Helmholtz shift: the operator of every level becomes A = coeff * (Laplacian_h - sigma I), i.e. -Laplacian + sigma
+ * for coeff = -1 (with mg_set_coefficient: -div(a grad .) + sigma); sigma >= 0, 0 restores the reference's operator.
+ * The shift only moves the stencil diagonal, so all kernels (fused legs and LDS tail included) serve it unchanged.
+ * This is the linear system of an implicit heat-equation step, (-Laplacian + 1/(alpha dt)) u = rhs / (alpha dt):
+ * applications/heat_equation.py:209-220, 254-261 set it up and then relax it with plain Gauss-Seidel
+ * (_solve_helmholtz, :459-497) because the reference's multigrid cannot shift its operator. */
+int mg_set_shift(mg_handle* h, double sigma);
+
 /* Device-resident stepping (benchmarks, preconditioner-style callers: fixed cycle counts, no transfer). */
 int mg_set_rhs(mg_handle* h, const void* rhs, int host_dtype);
 int mg_set_solution(mg_handle* h, const void* u0_or_null, int host_dtype);
@@ -172,6 +180,10 @@ int mg_op_norm(int dtype, int nx, int ny, double hx, double hy, const void* fiel
 int mg_op_jacobi(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* u, const void* rhs, void* out);
 /* replaces: solvers/smoothers.py:117-151,175-207, gpu/cuda_kernels.py:348-390 (red_black_gauss_seidel) */
 int mg_op_rbgs(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* u, const void* rhs, void* out);
+/* shifted operator on host arrays -- op 0: out = f - A_sigma u; 1: nu weighted-Jacobi sweeps; 2: nu red-black GS sweeps
+ * (the sweeps divide by 2/hx^2 + 2/hy^2 + sigma).  See mg_set_shift. */
+int mg_op_helmholtz(int dtype, int op, int nx, int ny, double hx, double hy, double coeff, double sigma, double omega, int nu,
+                    const void* u, const void* f, void* out);
 /* variable-coefficient forms of residual / Jacobi / red-black GS (no reference counterpart, see mg_set_coefficient) */
 int mg_op_residual_var(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* a, const void* u, const void* f, void* r);
 int mg_op_jacobi_var(int dtype, int nx, int ny, double hx, double hy, double omega, int nu, const void* a, const void* u, const void* rhs, void* out);

@@ -7,22 +7,25 @@ MultigridSolver, GPUMultigridSolver) plus the README facade (MixedPrecisionMulti
 PoissonProblem).  Device side: csrc/ -> lib/libmghip.so, reached through the C ABI in
 include/mghip.h.  There is no CPU fallback for the device path."""
 from .grid import Grid
-from .operators import BaseOperator, DiffusionOperator, LaplacianOperator, ProlongationOperator, RestrictionOperator
+from .operators import (BaseOperator, DiffusionOperator, HelmholtzOperator, LaplacianOperator, ProlongationOperator,
+                        RestrictionOperator)
 from .precision import PrecisionLevel, PrecisionManager
 from .smoothers import (BaseSolver, ConvergenceHistory, EnhancedJacobiSolver, GaussSeidelSmoother,
                         IterativeSolver, JacobiSmoother, WeightedJacobiSmoother)
 from .solver import GPUMultigridSolver, MultigridCycle, MultigridSolver
 from .engine import MultigridEngine
 from .facade import MixedPrecisionMultigrid, PoissonProblem, default_max_levels
-from . import applications
+from . import applications, heat_equation
+from .heat_equation import HeatEquationConfig, HeatEquationSolver, TimeSteppingScheme
 from .applications import MultigridPreconditioner, PoissonSolver2D
 
 __all__ = [
-    "Grid", "BaseOperator", "LaplacianOperator", "DiffusionOperator", "RestrictionOperator", "ProlongationOperator",
+    "Grid", "BaseOperator", "LaplacianOperator", "DiffusionOperator", "HelmholtzOperator", "RestrictionOperator", "ProlongationOperator",
     "PrecisionLevel", "PrecisionManager", "BaseSolver", "ConvergenceHistory", "IterativeSolver",
     "JacobiSmoother", "WeightedJacobiSmoother", "EnhancedJacobiSolver", "GaussSeidelSmoother",
     "MultigridSolver", "GPUMultigridSolver", "MultigridCycle", "MultigridEngine",
     "MixedPrecisionMultigrid", "PoissonProblem", "default_max_levels",
-    "PoissonSolver2D", "MultigridPreconditioner", "applications",
+    "PoissonSolver2D", "MultigridPreconditioner", "applications", "heat_equation", "HeatEquationSolver",
+    "HeatEquationConfig", "TimeSteppingScheme",
 ]
 __version__ = "0.1.0"

@@ -58,6 +58,7 @@ SIGNATURES = {
     "mg_solve": (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _pd, _i, _pi, _pi, C.POINTER(C.c_int32), C.POINTER(MgStats)]),
     "mg_iterate": (_i, [_vp, _d, _i, _pd, _i, _pi, _pi, C.POINTER(C.c_int32), C.POINTER(MgStats)]),
     "mg_set_coefficient": (_i, [_vp, _vp, _i]),
+    "mg_set_shift": (_i, [_vp, _d]),
     "mg_set_rhs": (_i, [_vp, _vp, _i]),
     "mg_set_solution": (_i, [_vp, _vp, _i]),
     "mg_get_solution": (_i, [_vp, _vp, _i]),
@@ -73,6 +74,7 @@ SIGNATURES = {
     "mg_op_norm": (_i, [_i, _i, _i, _d, _d, _vp, _pd]),
     "mg_op_jacobi": (_i, [_i, _i, _i, _d, _d, _d, _i, _vp, _vp, _vp]),
     "mg_op_rbgs": (_i, [_i, _i, _i, _d, _d, _d, _i, _vp, _vp, _vp]),
+    "mg_op_helmholtz": (_i, [_i, _i, _i, _i, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp]),
     "mg_op_residual_var": (_i, [_i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "mg_op_jacobi_var": (_i, [_i, _i, _i, _d, _d, _d, _i, _vp, _vp, _vp, _vp]),
     "mg_op_rbgs_var": (_i, [_i, _i, _i, _d, _d, _d, _i, _vp, _vp, _vp, _vp]),

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
                                                               int ny, int ld, T hx2, T hy2, T omega,
                                                               T one_m_omega, T diag, T coeff, double hxhy, double tol,
                                                               int maxit, int* __restrict__ sweeps_out,
-                                                              const T* __restrict__ a = nullptr) {
+                                                              const T* __restrict__ a = nullptr, T sigma = T(0)) {
   __shared__ double red[kBlock / 64];
   __shared__ double total;
   int it = 0;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
           const T* q = a + (size_t)i * ld + j;
           const T aip = T(0.5) * (q[0] + q[ld]), aim = T(0.5) * (q[0] + q[-ld]), ajp = T(0.5) * (q[0] + q[1]), ajm = T(0.5) * (q[0] + q[-1]);
           const T nb = (aip * p[ld] + aim * p[-ld]) / hx2 + (ajp * p[1] + ajm * p[-1]) / hy2;
-          const T D = (aip + aim) / hx2 + (ajp + ajm) / hy2;
+          const T D = (aip + aim) / hx2 + (ajp + ajm) / hy2 + sigma;
           const T un = (rhs[(size_t)i * ld + j] + nb) / D;
           p[0] = one_m_omega * p[0] + omega * un;
           continue;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
         if (a) {
           const T* q = a + (size_t)i * ld + j;
           const T aip = T(0.5) * (q[0] + q[ld]), aim = T(0.5) * (q[0] + q[-ld]), ajp = T(0.5) * (q[0] + q[1]), ajm = T(0.5) * (q[0] + q[-1]);
-          const T D = (aip + aim) / hx2 + (ajp + ajm) / hy2;
+          const T D = (aip + aim) / hx2 + (ajp + ajm) / hy2 + sigma;
           rv = rv - coeff * (((aip * p[ld] + aim * p[-ld]) / hx2 + (ajp * p[1] + ajm * p[-1]) / hy2) - p[0] * D);
         } else {
           rv = rv - coeff * (((p[ld] + p[-ld]) / hx2 + (p[1] + p[-1]) / hy2) - p[0] * diag);
@@ -759,7 +759,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void varcoef_kernel(const T* u_in, const T* __restrict__ a_in,
                                                          const T* __restrict__ rhs, T* out,   // out == u_in for red-black GS
                                                          double* __restrict__ partials, TileGeom g, T ihx2, T ihy2,
-                                                         T omega, T one_m_omega, T coeff, int colour, int poff) {
+                                                         T omega, T one_m_omega, T coeff, int colour, int poff,
+                                                         T sigma) {   // Helmholtz shift added to the diagonal (0: none)
   using S = TileShape<T>;
   __shared__ __attribute__((aligned(16))) T s[S::LDS_ELEMS];
   __shared__ __attribute__((aligned(16))) T sa[S::LDS_ELEMS];
@@ -807,7 +808,8 @@ __global__ __launch_bounds__(kBlock) void varcoef_kernel(const T* u_in, const T*
       const T ajp = T(0.5) * (amid.v[e] + ae), ajm = T(0.5) * (amid.v[e] + aw);
       const T sx = aip * dn.v[e] + aim * up.v[e];
       const T sy = ajp * ea + ajm * w;
-      const T D = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+      const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+      const T D = (sigma != T(0)) ? D0 + sigma : D0;
       const int gj = gj0 + e;
       const bool interior = row_in && gj >= 1 && gj < g.ny - 1;
       if (MODE == kVarJacobi || MODE == kVarRbgs) {

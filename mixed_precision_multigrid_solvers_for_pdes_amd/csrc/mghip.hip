@@ -70,11 +70,14 @@ struct Coef {
   bool pow2;       // 1/diag is exact: multiply instead of divide
   bool all_pow2;   // hx^2, hy^2 and diag are all powers of two
 };
-inline Coef coefs(double hx, double hy) {
+// sigma: Helmholtz shift, A = coeff * (Laplacian_h - sigma I) (coeff = -1: -Laplacian + sigma); it only moves the
+// diagonal, so every constant-coefficient kernel serves the shifted operator unchanged (sigma = 0: the reference's).
+inline Coef coefs(double hx, double hy, double sigma = 0.0) {
   Coef c;
   c.ihx2 = 1.0 / (hx * hx);
   c.ihy2 = 1.0 / (hy * hy);
   c.diag = 2.0 / (hx * hx) + 2.0 / (hy * hy);   // operators/laplacian.py:76, smoothers.py:65
+  if (sigma != 0.0) c.diag += sigma;
   c.invD = 1.0 / c.diag;
   int e = 0;
   c.pow2 = std::frexp(c.diag, &e) == 0.5;
@@ -90,9 +93,9 @@ inline int grid_for(long long work_items) {
 // ------------------------------------------------------------------ typed launchers ------------
 template <typename T>
 void launch_jacobi(const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy,
-                   double omega, hipStream_t st, bool fine = false) {
+                   double omega, hipStream_t st, bool fine = false, double sigma = 0.0) {
   if (nx < 3 || ny < 3) return;
-  const Coef c = coefs(hx, hy);
+  const Coef c = coefs(hx, hy, sigma);
   const mg::TileGeom g = make_geom<T>(nx, ny, ld, true);
   auto k = c.pow2 ? (fine ? mg::jacobi_kernel<T, mg::kFineTag, false> : mg::jacobi_kernel<T, mg::kCoarseTag, false>)
                   : (fine ? mg::jacobi_kernel<T, mg::kFineTag, true> : mg::jacobi_kernel<T, mg::kCoarseTag, true>);
@@ -102,9 +105,9 @@ void launch_jacobi(const void* u, const void* rhs, void* out, int nx, int ny, in
 
 template <typename T>
 void launch_rbgs_colour(void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double omega,
-                        int colour, int poff, hipStream_t st, bool fine = false) {
+                        int colour, int poff, hipStream_t st, bool fine = false, double sigma = 0.0) {
   if (nx < 3 || ny < 3) return;
-  const Coef c = coefs(hx, hy);
+  const Coef c = coefs(hx, hy, sigma);
   const mg::TileGeom g = make_geom<T>(nx, ny, ld, true);
   auto k = c.pow2 ? (fine ? mg::rbgs_colour_kernel<T, mg::kFineTag, false> : mg::rbgs_colour_kernel<T, mg::kCoarseTag, false>)
                   : (fine ? mg::rbgs_colour_kernel<T, mg::kFineTag, true> : mg::rbgs_colour_kernel<T, mg::kCoarseTag, true>);
@@ -115,8 +118,8 @@ void launch_rbgs_colour(void* u, const void* rhs, int nx, int ny, int ld, double
 // returns the number of partials written (0 when NORM is off)
 template <typename T, bool WRITE_R, bool NORM>
 int launch_residual(const void* u, const void* f, void* r, double* partials, int nx, int ny, int ld, double hx,
-                    double hy, double coeff, hipStream_t st, bool fine = false) {
-  const Coef c = coefs(hx, hy);
+                    double hy, double coeff, hipStream_t st, bool fine = false, double sigma = 0.0) {
+  const Coef c = coefs(hx, hy, sigma);
   const mg::TileGeom g = make_geom<T>(nx, ny, ld, false);
   auto k = fine ? mg::residual_kernel<T, WRITE_R, NORM, mg::kFineTag> : mg::residual_kernel<T, WRITE_R, NORM, mg::kCoarseTag>;
   hipLaunchKernelGGL(k, dim3(g.ntiles), dim3(mg::kBlock), 0, st, (const T*)u,
@@ -162,13 +165,14 @@ void launch_convert(const void* in, void* out, int nx, int ny, int ldi, int ldo,
 
 template <typename T>
 void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff, double omega,
-                   double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false, const void* a = nullptr) {
-  const Coef c = coefs(hx, hy);
+                   double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false, const void* a = nullptr,
+                   double sigma = 0.0) {
+  const Coef c = coefs(hx, hy, sigma);
   if (a) {          // variable coefficient: the general one-workgroup kernel
     if (zero_init) (void)hipMemsetAsync(u, 0, (size_t)nx * ld * sizeof(T), st);
     hipLaunchKernelGGL(mg::coarse_lexgs_kernel<T>, dim3(1), dim3(mg::kBlock), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
                        (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol, maxit,
-                       sweeps_dev, (const T*)a);
+                       sweeps_dev, (const T*)a, (T)sigma);
     return;
   }
   if (nx * ny <= mg::kCoarseLdsCells) {
@@ -185,24 +189,24 @@ void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, 
 
 // ------------------------------------------------------------------ dtype dispatch --------------
 void d_jacobi(int dt, const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy,
-              double omega, hipStream_t st, bool fine = false) {
-  if (dt == MG_F32) launch_jacobi<float>(u, rhs, out, nx, ny, ld, hx, hy, omega, st, fine);
-  else launch_jacobi<double>(u, rhs, out, nx, ny, ld, hx, hy, omega, st, fine);
+              double omega, hipStream_t st, bool fine = false, double sigma = 0.0) {
+  if (dt == MG_F32) launch_jacobi<float>(u, rhs, out, nx, ny, ld, hx, hy, omega, st, fine, sigma);
+  else launch_jacobi<double>(u, rhs, out, nx, ny, ld, hx, hy, omega, st, fine, sigma);
 }
 void d_rbgs_colour(int dt, void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double omega,
-                   int colour, int poff, hipStream_t st, bool fine = false) {
-  if (dt == MG_F32) launch_rbgs_colour<float>(u, rhs, nx, ny, ld, hx, hy, omega, colour, poff, st, fine);
-  else launch_rbgs_colour<double>(u, rhs, nx, ny, ld, hx, hy, omega, colour, poff, st, fine);
+                   int colour, int poff, hipStream_t st, bool fine = false, double sigma = 0.0) {
+  if (dt == MG_F32) launch_rbgs_colour<float>(u, rhs, nx, ny, ld, hx, hy, omega, colour, poff, st, fine, sigma);
+  else launch_rbgs_colour<double>(u, rhs, nx, ny, ld, hx, hy, omega, colour, poff, st, fine, sigma);
 }
 void d_residual(int dt, const void* u, const void* f, void* r, int nx, int ny, int ld, double hx, double hy,
-                double coeff, hipStream_t st, bool fine = false) {
-  if (dt == MG_F32) launch_residual<float, true, false>(u, f, r, nullptr, nx, ny, ld, hx, hy, coeff, st, fine);
-  else launch_residual<double, true, false>(u, f, r, nullptr, nx, ny, ld, hx, hy, coeff, st, fine);
+                double coeff, hipStream_t st, bool fine = false, double sigma = 0.0) {
+  if (dt == MG_F32) launch_residual<float, true, false>(u, f, r, nullptr, nx, ny, ld, hx, hy, coeff, st, fine, sigma);
+  else launch_residual<double, true, false>(u, f, r, nullptr, nx, ny, ld, hx, hy, coeff, st, fine, sigma);
 }
 int d_residual_norm(int dt, const void* u, const void* f, double* partials, int nx, int ny, int ld, double hx,
-                    double hy, double coeff, hipStream_t st, bool fine = false) {
-  if (dt == MG_F32) return launch_residual<float, false, true>(u, f, nullptr, partials, nx, ny, ld, hx, hy, coeff, st, fine);
-  return launch_residual<double, false, true>(u, f, nullptr, partials, nx, ny, ld, hx, hy, coeff, st, fine);
+                    double hy, double coeff, hipStream_t st, bool fine = false, double sigma = 0.0) {
+  if (dt == MG_F32) return launch_residual<float, false, true>(u, f, nullptr, partials, nx, ny, ld, hx, hy, coeff, st, fine, sigma);
+  return launch_residual<double, false, true>(u, f, nullptr, partials, nx, ny, ld, hx, hy, coeff, st, fine, sigma);
 }
 int d_sumsq(int dt, const void* x, double* partials, int ld, int i_lo, int i_hi, int j_lo, int j_hi, hipStream_t st) {
   return dt == MG_F32 ? launch_sumsq<float>(x, partials, ld, i_lo, i_hi, j_lo, j_hi, st)
@@ -245,9 +249,9 @@ void d_convert(int di, int dout, const void* in, void* out, int nx, int ny, int 
 }
 void d_coarse(int dt, void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff,
               double omega, double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false,
-              const void* a = nullptr) {
-  if (dt == MG_F32) launch_coarse<float>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init, a);
-  else launch_coarse<double>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init, a);
+              const void* a = nullptr, double sigma = 0.0) {
+  if (dt == MG_F32) launch_coarse<float>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init, a, sigma);
+  else launch_coarse<double>(u, rhs, nx, ny, ld, hx, hy, coeff, omega, tol, maxit, sweeps_dev, st, zero_init, a, sigma);
 }
 
 
@@ -255,21 +259,21 @@ void d_coarse(int dt, void* u, const void* rhs, int nx, int ny, int ld, double h
 // ------------------------------------------------------------------ variable coefficient ------
 template <typename T, int MODE>
 int launch_var(const void* u, const void* a, const void* f, void* out, double* partials, int nx, int ny, int ld, double hx,
-               double hy, double omega, double coeff, int colour, int poff, hipStream_t st) {
+               double hy, double omega, double coeff, int colour, int poff, hipStream_t st, double sigma = 0.0) {
   if (nx < 3 || ny < 3) return 0;
   const Coef c = coefs(hx, hy);
   const bool interior_only = (MODE == mg::kVarJacobi || MODE == mg::kVarRbgs);
   const mg::TileGeom g = make_geom<T>(nx, ny, ld, interior_only);
   hipLaunchKernelGGL((mg::varcoef_kernel<T, MODE>), dim3(g.ntiles), dim3(mg::kBlock), 0, st, (const T*)u, (const T*)a,
                      (const T*)f, (T*)out, partials, g, (T)c.ihx2, (T)c.ihy2, (T)omega, (T)(1.0 - omega), (T)coeff, colour,
-                     poff & 1);
+                     poff & 1, (T)sigma);
   return g.ntiles;
 }
 template <int MODE>
 int d_var(int dt, const void* u, const void* a, const void* f, void* out, double* partials, int nx, int ny, int ld, double hx,
-          double hy, double omega, double coeff, int colour, int poff, hipStream_t st) {
-  return dt == MG_F32 ? launch_var<float, MODE>(u, a, f, out, partials, nx, ny, ld, hx, hy, omega, coeff, colour, poff, st)
-                      : launch_var<double, MODE>(u, a, f, out, partials, nx, ny, ld, hx, hy, omega, coeff, colour, poff, st);
+          double hy, double omega, double coeff, int colour, int poff, hipStream_t st, double sigma = 0.0) {
+  return dt == MG_F32 ? launch_var<float, MODE>(u, a, f, out, partials, nx, ny, ld, hx, hy, omega, coeff, colour, poff, st, sigma)
+                      : launch_var<double, MODE>(u, a, f, out, partials, nx, ny, ld, hx, hy, omega, coeff, colour, poff, st, sigma);
 }
 template <typename TI, typename TO>
 void launch_inject(const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
@@ -311,6 +315,7 @@ struct LegGeom {      // what every fused launch needs
   int ci_off = 0, cj_off = 0, sides = mg::kAllSides;
   int ni_lo = -1, ni_hi = -1, nj_lo = -1, nj_hi = -1;     // norm window; -1: the interior
   int select = 0, in_i_lo = 0, in_i_hi = 0, in_j_lo = 0, in_j_hi = 0;   // tile selection (see mg::FusedArgs)
+  double sigma = 0.0;                                                    // Helmholtz shift (see coefs)
 };
 inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
   a.ci_off = g.ci_off; a.cj_off = g.cj_off; a.sides = g.sides;
@@ -322,7 +327,7 @@ inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
 template <typename T, typename TX, int SM>
 void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
   constexpr int HALO = 2 * mg::sweep_halo(SM) + 2;
-  const Coef c = coefs(g.hx, g.hy);
+  const Coef c = coefs(g.hx, g.hy, g.sigma);
   mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
   apply_sub(a, g);
   void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T);
@@ -339,7 +344,7 @@ void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const L
 template <typename T, typename TX, typename TC, int SM>
 int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm,
               hipStream_t st) {
-  const Coef c = coefs(g.hx, g.hy);
+  const Coef c = coefs(g.hx, g.hy, g.sigma);
   if (norm) {
     constexpr int HALO = 2 * mg::sweep_halo(SM) + 1;
     mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
@@ -364,7 +369,7 @@ int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double
 template <typename T, int SM>
 void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
   constexpr int HALO = 2 * mg::sweep_halo(SM);
-  const Coef c = coefs(g.hx, g.hy);
+  const Coef c = coefs(g.hx, g.hy, g.sigma);
   const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, 0, 0, 0, g.poff);
   auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM>
                   : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 0, SM>;
@@ -489,6 +494,7 @@ struct mg_handle {
   bool promoted = false;        // one-way rule: fp32 -> fp64 happened
   bool have_rhs = false;
   bool varcoef = false;          // A = coeff * div(a grad .) with the per-level fields lv[l].a
+  double sigma = 0.0;            // Helmholtz shift: A = coeff * (Laplacian - sigma I) on every level (mg_set_shift)
   double ring_sumsq[2] = {0, 0};   // sum of f^2 over the boundary ring of the fine rhs, per dtype (r = f there)
   int norm_partials = 0;           // > 0: `partials` holds sum r^2 over interior cells of the CURRENT fine iterate
   int tail_start = -1;             // first level of the single-workgroup LDS tail (-1: none)
@@ -566,22 +572,22 @@ void smooth(mg_handle* h, int l, int nu) {
   for (int s = 0; s < nu; ++s) {
     if (h->varcoef && h->cfg.smoother == MG_JACOBI) {
       d_var<mg::kVarJacobi>(dt, v.u[dt], v.a[dt], v.rhs[dt], v.t[dt], nullptr, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega,
-                            h->cfg.coeff, 0, 0, h->stream);
+                            h->cfg.coeff, 0, 0, h->stream, h->sigma);
       std::swap(v.u[dt], v.t[dt]);
     } else if (h->varcoef && h->cfg.smoother == MG_RBGS) {
       for (int colour = 0; colour < 2; ++colour)
         d_var<mg::kVarRbgs>(dt, v.u[dt], v.a[dt], v.rhs[dt], v.u[dt], nullptr, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega,
-                            h->cfg.coeff, colour, h->cfg.colour_offset, h->stream);
+                            h->cfg.coeff, colour, h->cfg.colour_offset, h->stream, h->sigma);
     } else if (h->cfg.smoother == MG_JACOBI) {
-      d_jacobi(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, l == 0);
+      d_jacobi(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, l == 0, h->sigma);
       std::swap(v.u[dt], v.t[dt]);
     } else if (h->cfg.smoother == MG_RBGS) {
       for (int colour = 0; colour < 2; ++colour)
         d_rbgs_colour(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, colour,
-                      h->cfg.colour_offset, h->stream, l == 0);
+                      h->cfg.colour_offset, h->stream, l == 0, h->sigma);
     } else {   // MG_LEXGS: exactly `nu` sweeps (tol < 0 never triggers the early exit)
       d_coarse(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, h->cfg.omega, -1.0, nu - s,
-               nullptr, h->stream, false, h->varcoef ? v.a[dt] : nullptr);
+               nullptr, h->stream, false, h->varcoef ? v.a[dt] : nullptr, h->sigma);
       break;
     }
   }
@@ -592,7 +598,7 @@ void coarse_solve(mg_handle* h, int l, bool zero_init = false) {
   const int dt = h->level_dtype(l);
   // solvers/multigrid.py:119-124: the default coarse solver is GaussSeidelSmoother(omega = 1)
   d_coarse(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, 1.0, h->cfg.coarse_tol,
-           h->cfg.coarse_maxit, h->d_int, h->stream, zero_init, h->varcoef ? v.a[dt] : nullptr);
+           h->cfg.coarse_maxit, h->d_int, h->stream, zero_init, h->varcoef ? v.a[dt] : nullptr, h->sigma);
 }
 
 int cycle(mg_handle* h, int l) {
@@ -606,9 +612,9 @@ int cycle(mg_handle* h, int l) {
     StageTimer tm(h, &f, 1);
     if (h->varcoef)
       d_var<mg::kVarResidual>(dt, f.u[dt], f.a[dt], f.rhs[dt], f.r[dt], nullptr, f.nx, f.ny, f.ld[dt], f.hx, f.hy, 1.0,
-                              h->cfg.coeff, 0, 0, h->stream);
+                              h->cfg.coeff, 0, 0, h->stream, h->sigma);
     else
-      d_residual(dt, f.u[dt], f.rhs[dt], f.r[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.coeff, h->stream, l == 0);
+      d_residual(dt, f.u[dt], f.rhs[dt], f.r[dt], f.nx, f.ny, f.ld[dt], f.hx, f.hy, h->cfg.coeff, h->stream, l == 0, h->sigma);
     d_restrict(dt, dc, f.r[dt], c.rhs[dc], f.nx, f.ny, f.ld[dt], c.ld[dc], h->stream);
   }
   (void)hipMemsetAsync(c.u[dc], 0, (size_t)c.nx * c.ld[dc] * esize(dc), h->stream);
@@ -701,7 +707,7 @@ int launch_tail(mg_handle* h, bool zero_top) {
   for (int l = k; l < L; ++l) {
     const Level& v = h->lv[l];
     mg::TailLevel& t = a.lv[l - k];
-    const Coef c = coefs(v.hx, v.hy);
+    const Coef c = coefs(v.hx, v.hy, h->sigma);
     t.nx = v.nx; t.ny = v.ny; t.off = (int)off;
     t.ihx2 = c.ihx2; t.ihy2 = c.ihy2; t.invD = c.invD; t.diag = c.diag; t.hx2 = v.hx * v.hx; t.hy2 = v.hy * v.hy;
     t.hxhy = v.hx * v.hy; t.use_div = c.pow2 ? 0 : 1; t.exact_recip = c.all_pow2 ? 1 : 0;
@@ -745,6 +751,7 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   const bool fine = (l == 0);
   const int sm = h->cfg.smoother;
   LegGeom g{f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, 0, h->cfg.colour_offset, fine};
+  g.sigma = h->sigma;
   if (part != kPartBack) {
     StageTimer tm(h, &f, 0);
     int extra = std::max(0, h->cfg.pre - 2);
@@ -904,8 +911,9 @@ int fine_norm(mg_handle* h, double* out) {
   }
   const int n = h->varcoef
       ? d_var<mg::kVarResidualNorm>(dt, v.u[dt], v.a[dt], v.rhs[dt], nullptr, h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy,
-                                    1.0, h->cfg.coeff, 0, 0, h->stream)
-      : d_residual_norm(dt, v.u[dt], v.rhs[dt], h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, h->stream, true);
+                                    1.0, h->cfg.coeff, 0, 0, h->stream, h->sigma)
+      : d_residual_norm(dt, v.u[dt], v.rhs[dt], h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.coeff, h->stream, true,
+                        h->sigma);
   double ss = 0;
   const int rc = reduce_to_host(h, n, &ss);
   if (rc != MG_OK) return rc;
@@ -1250,6 +1258,14 @@ int mg_set_coefficient(mg_handle* h, const void* a_host, int host_dtype) {
   return MG_OK;
 }
 
+int mg_set_shift(mg_handle* h, double sigma) {
+  if (!h || !(sigma >= 0.0) || !std::isfinite(sigma))
+    return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_shift: sigma must be finite and >= 0");
+  h->sigma = sigma;
+  h->norm_partials = 0;     // a cached sum r^2 belongs to the previous operator
+  return MG_OK;
+}
+
 int mg_set_solution(mg_handle* h, const void* u0, int host_dtype) {
   if (!h || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_solution: bad argument");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
@@ -1459,14 +1475,14 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
                   if (d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], v.u[dt], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE; } break;
         case 6: { const int rc = run_cycle(h); if (rc != MG_OK) return rc; } break;
         case 7: { Level& c = h->lv[level + 1]; const int dc = c.rhs[dt] ? dt : 1 - dt;          // down leg
-                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0};
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma;
                   d_down(h->cfg.smoother, dt, dc, v.u[dt], v.rhs[dt], v.t[dt], c.rhs[dc], g, false, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         case 8: { Level& c = h->lv[level + 1]; const int dc = c.u[dt] ? dt : 1 - dt;            // up leg (+ norm on level 0)
-                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0};
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma;
                   if (d_up(h->cfg.smoother, dt, dc, h->grid_dtype, v.u[dt], v.rhs[dt], v.t[dt], c.u[dc], h->partials, g, level == 0, h->stream) < 0) return MG_ERR_INVALID_VALUE;
                   std::swap(v.u[dt], v.t[dt]); } break;
-        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0};
+        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma;
                   d_sweeps(h->cfg.smoother, dt, v.u[dt], v.rhs[dt], v.t[dt], g, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         default: return MG_ERR_INVALID_VALUE;
@@ -1702,6 +1718,26 @@ int mg_op_rbgs(int dtype, int nx, int ny, double hx, double hy, double omega, in
   return down(out, dtype, da, nx, ny);
 }
 
+
+int mg_op_helmholtz(int dtype, int op, int nx, int ny, double hx, double hy, double coeff, double sigma, double omega, int nu,
+                    const void* u, const void* f, void* out) {
+  CHECK_DEV(valid_dtype(dtype) && u && f && out && nu >= 0 && nx >= 3 && ny >= 3 && op >= 0 && op <= 2 && sigma >= 0.0,
+            "mg_op_helmholtz: bad argument");
+  RC(need_device());
+  const int ld = pitch_elems(dtype, ny);
+  Scratch s; void *da, *db, *df;
+  RC(s.get(&da, dtype, nx, ny)); RC(s.get(&db, dtype, nx, ny)); RC(s.get(&df, dtype, nx, ny));
+  RC(up(da, dtype, u, nx, ny)); RC(up(db, dtype, u, nx, ny)); RC(up(df, dtype, f, nx, ny));
+  if (op == 0) {
+    d_residual(dtype, da, df, db, nx, ny, ld, hx, hy, coeff, nullptr, false, sigma);
+    return down(out, dtype, db, nx, ny);
+  }
+  for (int k = 0; k < nu; ++k) {
+    if (op == 1) { d_jacobi(dtype, da, df, db, nx, ny, ld, hx, hy, omega, nullptr, false, sigma); std::swap(da, db); }
+    else for (int c = 0; c < 2; ++c) d_rbgs_colour(dtype, da, df, nx, ny, ld, hx, hy, omega, c, 0, nullptr, false, sigma);
+  }
+  return down(out, dtype, da, nx, ny);
+}
 
 int mg_op_residual_var(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* a, const void* u, const void* f, void* r) {
   CHECK_DEV(valid_dtype(dtype) && a && u && f && r && nx >= 3 && ny >= 3, "mg_op_residual_var: bad argument");

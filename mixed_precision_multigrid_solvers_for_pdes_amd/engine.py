@@ -110,6 +110,10 @@ class MultigridEngine:
             raise ValueError(f"coefficient shape {a.shape} doesn't match grid shape {(self.nx, self.ny)}")
         self._check(self._lib.mg_set_coefficient(self._h, _lib.ptr(a), _lib.dtype_code(a.dtype)))
 
+    def set_shift(self, sigma):
+        """Helmholtz shift: every level's operator becomes coeff * (Laplacian - sigma I) (include/mghip.h: mg_set_shift)."""
+        self._check(self._lib.mg_set_shift(self._h, float(sigma)))
+
     # ---- device-resident stepping ---------------------------------------------------------
     def set_rhs(self, rhs):
         rhs = _lib.as_c(rhs)

@@ -116,6 +116,38 @@ class ProlongationOperator(BaseOperator):
         return out
 
 
+class HelmholtzOperator(LaplacianOperator):
+    """A u = coefficient * (Laplacian_h u - shift * u): for coefficient = -1 the SPD operator -Laplacian + shift of
+    an implicit heat-equation step (applications/heat_equation.py:209-220 builds this system and, lacking a shifted
+    multigrid, relaxes it with Gauss-Seidel, :459-497).  shift = 0 is LaplacianOperator(coefficient) bit for bit."""
+
+    def __init__(self, shift, coefficient=-1.0):
+        if not shift >= 0:
+            raise ValueError("the Helmholtz shift must be >= 0")
+        super().__init__(coefficient)
+        self.name = f"Helmholtz(coeff={coefficient}, shift={shift})"
+        self.shift = float(shift)
+
+    def residual(self, grid, u, f):
+        u, f = _lib.as_c(u), _lib.as_c(f)
+        dt = np.result_type(u.dtype, f.dtype)
+        u, f = np.ascontiguousarray(u, dtype=dt), np.ascontiguousarray(f, dtype=dt)
+        self._check(grid, u)
+        self._check(grid, f)
+        r = np.empty_like(u)
+        _lib.check(_lib.load().mg_op_helmholtz(_lib.dtype_code(dt), 0, grid.nx, grid.ny, grid.hx, grid.hy,
+                                               float(self.coefficient), self.shift, 1.0, 0, _lib.ptr(u), _lib.ptr(f), _lib.ptr(r)))
+        grid.residual = r.copy()
+        return r
+
+    def apply(self, grid, field=None):
+        u = _lib.as_c(grid.values if field is None else field)
+        saved = grid._residual
+        out = -self.residual(grid, u, np.zeros_like(u))   # boundary rows / columns 0 like LaplacianOperator.apply
+        grid._residual = saved
+        return out
+
+
 class DiffusionOperator(BaseOperator):
     """A u = coefficient * div(a grad u)  (coefficient = -1: the SPD operator -div(a grad u)).
 

@@ -137,6 +137,11 @@ class JacobiSmoother(IterativeSolver):                                       # s
                                                     float(self.omega), int(num_iterations), _lib.ptr(a), _lib.ptr(u),
                                                     _lib.ptr(rhs), _lib.ptr(out)))
             return out
+        if getattr(operator, "shift", 0.0):            # HelmholtzOperator: the shift joins the divisor
+            _lib.check(_lib.load().mg_op_helmholtz(_lib.dtype_code(u.dtype), 1, grid.nx, grid.ny, grid.hx, grid.hy, -1.0,
+                                                   float(operator.shift), float(self.omega), int(num_iterations),
+                                                   _lib.ptr(u), _lib.ptr(rhs), _lib.ptr(out)))
+            return out
         _lib.check(_lib.load().mg_op_jacobi(_lib.dtype_code(u.dtype), grid.nx, grid.ny, grid.hx, grid.hy,
                                             float(self.omega), int(num_iterations), _lib.ptr(u), _lib.ptr(rhs),
                                             _lib.ptr(out)))
@@ -175,6 +180,10 @@ class GaussSeidelSmoother(IterativeSolver):                                  # s
             a = operator.field(grid, u.dtype)
             _lib.check(lib.mg_op_rbgs_var(_lib.dtype_code(u.dtype), grid.nx, grid.ny, grid.hx, grid.hy, float(self.omega),
                                           int(num_iterations), _lib.ptr(a), _lib.ptr(u), _lib.ptr(rhs), _lib.ptr(out)))
+        elif self.red_black and getattr(operator, "shift", 0.0):
+            _lib.check(lib.mg_op_helmholtz(_lib.dtype_code(u.dtype), 2, grid.nx, grid.ny, grid.hx, grid.hy, -1.0,
+                                           float(operator.shift), float(self.omega), int(num_iterations), _lib.ptr(u),
+                                           _lib.ptr(rhs), _lib.ptr(out)))
         elif self.red_black:
             _lib.check(lib.mg_op_rbgs(_lib.dtype_code(u.dtype), grid.nx, grid.ny, grid.hx, grid.hy,
                                       float(self.omega), int(num_iterations), _lib.ptr(u), _lib.ptr(rhs),

@@ -134,6 +134,7 @@ class MultigridSolver(BaseSolver):
         self.reset()
         pm = precision_manager
         eng = self._engine(grid, pm)
+        eng.set_shift(getattr(operator, "shift", 0.0))     # HelmholtzOperator: may change between solves (time steppers)
         rhs = np.asarray(rhs)
         work_dtype = np.float32 if np.dtype(grid.dtype) == np.float32 and rhs.dtype == np.float32 else np.float64
         t0 = time.time()

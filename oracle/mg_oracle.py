@@ -63,20 +63,22 @@ def hierarchy_shapes(nx, ny, max_levels):
 # a2/a3  Operator and residual -- operators/laplacian.py:44-80, 105-124
 # --------------------------------------------------------------------------
 
-def apply_laplacian(u, hx, hy, coeff=-1.0):
-    """LaplacianOperator.apply: coeff * 5-point stencil, zero on the boundary."""
+def apply_laplacian(u, hx, hy, coeff=-1.0, shift=0.0):
+    """LaplacianOperator.apply: coeff * 5-point stencil, zero on the boundary.
+    shift (ours, not in the reference; 0 = the reference): A = coeff * (Laplacian_h - shift I), the Helmholtz
+    operator of an implicit heat step -- the shift only joins the diagonal, here and in every smoother below."""
     out = np.zeros_like(u)
     out[1:-1, 1:-1] = coeff * (
         (u[2:, 1:-1] + u[:-2, 1:-1]) / hx**2
         + (u[1:-1, 2:] + u[1:-1, :-2]) / hy**2
-        - u[1:-1, 1:-1] * (2.0 / hx**2 + 2.0 / hy**2)
+        - u[1:-1, 1:-1] * (2.0 / hx**2 + 2.0 / hy**2 + shift)
     )
     return out
 
 
-def residual(u, f, hx, hy, coeff=-1.0):
+def residual(u, f, hx, hy, coeff=-1.0, shift=0.0):
     """LaplacianOperator.residual: r = f - A u at every cell (boundary r = f)."""
-    return f - apply_laplacian(u, hx, hy, coeff)
+    return f - apply_laplacian(u, hx, hy, coeff, shift)
 
 
 # --------------------------------------------------------------------------
@@ -94,10 +96,10 @@ def l2_norm(field, hx, hy):
 #     (vectorised twin).  The two differ only in "/ hx**2" vs "* (1/hx**2)".
 # --------------------------------------------------------------------------
 
-def jacobi(u, rhs, hx, hy, omega, nu=1, form="loop"):
+def jacobi(u, rhs, hx, hy, omega, nu=1, form="loop", shift=0.0):
     u = u.copy()
     if form == "loop":          # smoothers.py:65-83
-        diag = -2.0 / hx**2 - 2.0 / hy**2
+        diag = -2.0 / hx**2 - 2.0 / hy**2 - shift
         for _ in range(nu):
             old = u.copy()
             nb = (old[2:, 1:-1] + old[:-2, 1:-1]) / hx**2 + (old[1:-1, 2:] + old[1:-1, :-2]) / hy**2
@@ -105,7 +107,7 @@ def jacobi(u, rhs, hx, hy, omega, nu=1, form="loop"):
             u[1:-1, 1:-1] = (1 - omega) * old[1:-1, 1:-1] + omega * new
     elif form == "vectorized":  # iterative.py:84-104
         hx2_inv, hy2_inv = 1.0 / (hx**2), 1.0 / (hy**2)
-        diag = -(2.0 * hx2_inv + 2.0 * hy2_inv)
+        diag = -(2.0 * hx2_inv + 2.0 * hy2_inv + shift)
         for _ in range(nu):
             old = u.copy()
             nb = hx2_inv * (old[2:, 1:-1] + old[:-2, 1:-1]) + hy2_inv * (old[1:-1, 2:] + old[1:-1, :-2])
@@ -128,9 +130,9 @@ def _colour_mask(shape, colour):
     return ((i + j) % 2) == colour
 
 
-def rbgs(u, rhs, hx, hy, omega=1.0, nu=1):
+def rbgs(u, rhs, hx, hy, omega=1.0, nu=1, shift=0.0):
     u = u.copy()
-    diag = -2.0 / hx**2 - 2.0 / hy**2
+    diag = -2.0 / hx**2 - 2.0 / hy**2 - shift
     masks = (_colour_mask(u.shape, 0), _colour_mask(u.shape, 1))
     for _ in range(nu):
         for m in masks:
@@ -151,9 +153,9 @@ def rbgs(u, rhs, hx, hy, omega=1.0, nu=1):
 #     sweep over anti-diagonals reproduces the lexicographic loop exactly.
 # --------------------------------------------------------------------------
 
-def lexgs_sweep(u, rhs, hx, hy, omega=1.0):
+def lexgs_sweep(u, rhs, hx, hy, omega=1.0, shift=0.0):
     nx, ny = u.shape
-    diag = -2.0 / hx**2 - 2.0 / hy**2
+    diag = -2.0 / hx**2 - 2.0 / hy**2 - shift
     for s in range(2, nx + ny - 3):
         i = np.arange(max(1, s - (ny - 2)), min(nx - 2, s - 1) + 1)
         j = s - i
@@ -163,15 +165,15 @@ def lexgs_sweep(u, rhs, hx, hy, omega=1.0):
     return u
 
 
-def coarse_solve(u0, rhs, hx, hy, coeff=-1.0, tol=1e-12, maxit=1000, omega=1.0):
+def coarse_solve(u0, rhs, hx, hy, coeff=-1.0, tol=1e-12, maxit=1000, omega=1.0, shift=0.0):
     """IterativeSolver.solve with the lex-GS smoother (base.py:255-290):
     sweep, residual, norm, stop when norm < tol or after maxit sweeps.
     Returns (u, sweeps)."""
     u = u0.copy()
     it = 0
     for it in range(1, maxit + 1):
-        u = lexgs_sweep(u.copy(), rhs, hx, hy, omega)
-        if l2_norm(residual(u, rhs, hx, hy, coeff), hx, hy) < tol:
+        u = lexgs_sweep(u.copy(), rhs, hx, hy, omega, shift)
+        if l2_norm(residual(u, rhs, hx, hy, coeff, shift), hx, hy) < tol:
             break
     return u, it
 
@@ -274,9 +276,10 @@ class MGOracle:
 
     def __init__(self, nx, ny, domain=(0.0, 1.0, 0.0, 1.0), dtype=np.float64, coeff=-1.0,
                  max_levels=4, cycle="V", pre=2, post=2, smoother="jacobi", omega=0.8,
-                 jacobi_form="loop", coarse_tol=1e-12, coarse_maxit=1000):
+                 jacobi_form="loop", coarse_tol=1e-12, coarse_maxit=1000, shift=0.0):
         self.dtype = np.dtype(dtype)
         self.coeff = coeff
+        self.shift = shift                         # Helmholtz shift on every level (0: the reference's operator)
         self.cycle = cycle
         self.pre, self.post = pre, post
         self.smoother, self.omega, self.jform = smoother, omega, jacobi_form
@@ -290,26 +293,26 @@ class MGOracle:
     def _smooth(self, u, level, nu):
         hx, hy = self.h[level]
         if self.smoother == "jacobi":
-            return jacobi(u, self.rhs[level], hx, hy, self.omega, nu, self.jform)
+            return jacobi(u, self.rhs[level], hx, hy, self.omega, nu, self.jform, self.shift)
         if self.smoother == "rbgs":
-            return rbgs(u, self.rhs[level], hx, hy, self.omega, nu)
+            return rbgs(u, self.rhs[level], hx, hy, self.omega, nu, self.shift)
         if self.smoother == "lexgs":
             u = u.copy()
             for _ in range(nu):
-                lexgs_sweep(u, self.rhs[level], hx, hy, self.omega)
+                lexgs_sweep(u, self.rhs[level], hx, hy, self.omega, self.shift)
             return u
         raise ValueError(self.smoother)
 
     def residual_norm(self, u, rhs, level=0):      # multigrid.py:372-375
         hx, hy = self.h[level]
-        return float(l2_norm(residual(u, rhs, hx, hy, self.coeff), hx, hy))
+        return float(l2_norm(residual(u, rhs, hx, hy, self.coeff, self.shift), hx, hy))
 
     # -- cycle (multigrid.py:253-337) --------------------------------------
     def cycle_once(self, u, level=0, pm=None):
         L = len(self.shapes)
         hx, hy = self.h[level]
         if level == L - 1:                         # multigrid.py:270-272, 355-370
-            u, sweeps = coarse_solve(u, self.rhs[level], hx, hy, self.coeff, self.ctol, self.cmaxit)
+            u, sweeps = coarse_solve(u, self.rhs[level], hx, hy, self.coeff, self.ctol, self.cmaxit, shift=self.shift)
             self.coarse_sweeps.append(sweeps)
             return u
         if pm is not None:                         # multigrid.py:275-285
@@ -318,7 +321,7 @@ class MGOracle:
             self.rhs[level] = pm.convert(self.rhs[level], p)
         if self.pre > 0:
             u = self._smooth(u, level, self.pre)
-        r = residual(u, self.rhs[level], hx, hy, self.coeff)
+        r = residual(u, self.rhs[level], hx, hy, self.coeff, self.shift)
         self.rhs[level + 1] = restrict_fw(r, self.dtype).copy()     # :298-304
         e = np.zeros_like(self.rhs[level + 1])
         if self.cycle == "V":
@@ -346,7 +349,7 @@ class MGOracle:
             hier.append(restrict_fw(hier[-1], self.dtype))
         self.rhs[L - 1] = hier[-1].copy()
         hx, hy = self.h[L - 1]
-        u, _ = coarse_solve(np.zeros_like(hier[-1]), hier[-1], hx, hy, self.coeff, self.ctol, self.cmaxit)
+        u, _ = coarse_solve(np.zeros_like(hier[-1]), hier[-1], hx, hy, self.coeff, self.ctol, self.cmaxit, shift=self.shift)
         for level in range(L - 2, -1, -1):
             u = prolong_bilinear(u, self.dtype)
             if level == 0 and ring is not None:
@@ -391,46 +394,46 @@ def _faces(a):
     return 0.5 * (c + a[2:, 1:-1]), 0.5 * (c + a[:-2, 1:-1]), 0.5 * (c + a[1:-1, 2:]), 0.5 * (c + a[1:-1, :-2])
 
 
-def var_residual(u, f, a, hx, hy, coeff=-1.0):
+def var_residual(u, f, a, hx, hy, coeff=-1.0, shift=0.0):
     ihx2, ihy2 = 1.0 / (hx * hx), 1.0 / (hy * hy)
     aip, aim, ajp, ajm = _faces(a)
     sx = aip * u[2:, 1:-1] + aim * u[:-2, 1:-1]
     sy = ajp * u[1:-1, 2:] + ajm * u[1:-1, :-2]
-    D = (aip + aim) * ihx2 + (ajp + ajm) * ihy2
+    D = (aip + aim) * ihx2 + (ajp + ajm) * ihy2 + shift
     r = f.copy()
     r[1:-1, 1:-1] = f[1:-1, 1:-1] - coeff * ((sx * ihx2 + sy * ihy2) - u[1:-1, 1:-1] * D)
     return r
 
 
-def _var_update(u, f, a, hx, hy, omega):
+def _var_update(u, f, a, hx, hy, omega, shift=0.0):
     ihx2, ihy2 = 1.0 / (hx * hx), 1.0 / (hy * hy)
     aip, aim, ajp, ajm = _faces(a)
     sx = aip * u[2:, 1:-1] + aim * u[:-2, 1:-1]
     sy = ajp * u[1:-1, 2:] + ajm * u[1:-1, :-2]
-    D = (aip + aim) * ihx2 + (ajp + ajm) * ihy2
+    D = (aip + aim) * ihx2 + (ajp + ajm) * ihy2 + shift
     un = (f[1:-1, 1:-1] + (ihx2 * sx + ihy2 * sy)) / D
     return (1.0 - omega) * u[1:-1, 1:-1] + omega * un
 
 
-def var_jacobi(u, f, a, hx, hy, omega, nu=1):
+def var_jacobi(u, f, a, hx, hy, omega, nu=1, shift=0.0):
     u = u.copy()
     for _ in range(nu):
-        u[1:-1, 1:-1] = _var_update(u, f, a, hx, hy, omega)
+        u[1:-1, 1:-1] = _var_update(u, f, a, hx, hy, omega, shift)
     return u
 
 
-def var_rbgs(u, f, a, hx, hy, omega=1.0, nu=1):
+def var_rbgs(u, f, a, hx, hy, omega=1.0, nu=1, shift=0.0):
     u = u.copy()
     masks = (_colour_mask(u.shape, 0), _colour_mask(u.shape, 1))
     for _ in range(nu):
         for m in masks:
-            upd = _var_update(u, f, a, hx, hy, omega)
+            upd = _var_update(u, f, a, hx, hy, omega, shift)
             inner = u[1:-1, 1:-1]
             inner[m] = upd[m]
     return u
 
 
-def var_lexgs_sweep(u, f, a, hx, hy):
+def var_lexgs_sweep(u, f, a, hx, hy, shift=0.0):
     nx, ny = u.shape
     hx2, hy2 = hx * hx, hy * hy
     for s in range(2, nx + ny - 3):
@@ -439,15 +442,15 @@ def var_lexgs_sweep(u, f, a, hx, hy):
         aip, aim = 0.5 * (a[i, j] + a[i + 1, j]), 0.5 * (a[i, j] + a[i - 1, j])
         ajp, ajm = 0.5 * (a[i, j] + a[i, j + 1]), 0.5 * (a[i, j] + a[i, j - 1])
         nb = (aip * u[i + 1, j] + aim * u[i - 1, j]) / hx2 + (ajp * u[i, j + 1] + ajm * u[i, j - 1]) / hy2
-        D = (aip + aim) / hx2 + (ajp + ajm) / hy2
+        D = (aip + aim) / hx2 + (ajp + ajm) / hy2 + shift
         u[i, j] = (1 - 1.0) * u[i, j] + 1.0 * ((f[i, j] + nb) / D)
     return u
 
 
-def var_coarse_residual(u, f, a, hx, hy, coeff):
+def var_coarse_residual(u, f, a, hx, hy, coeff, shift=0.0):
     hx2, hy2 = hx * hx, hy * hy
     aip, aim, ajp, ajm = _faces(a)
-    D = (aip + aim) / hx2 + (ajp + ajm) / hy2
+    D = (aip + aim) / hx2 + (ajp + ajm) / hy2 + shift
     r = f.copy()
     r[1:-1, 1:-1] = f[1:-1, 1:-1] - coeff * (((aip * u[2:, 1:-1] + aim * u[:-2, 1:-1]) / hx2 +
                                                (ajp * u[1:-1, 2:] + ajm * u[1:-1, :-2]) / hy2) - u[1:-1, 1:-1] * D)
@@ -466,12 +469,12 @@ class VarMGOracle(MGOracle):
     def _smooth(self, u, level, nu):
         hx, hy = self.h[level]
         if self.smoother == "jacobi":
-            return var_jacobi(u, self.rhs[level], self.a[level], hx, hy, self.omega, nu)
-        return var_rbgs(u, self.rhs[level], self.a[level], hx, hy, self.omega, nu)
+            return var_jacobi(u, self.rhs[level], self.a[level], hx, hy, self.omega, nu, self.shift)
+        return var_rbgs(u, self.rhs[level], self.a[level], hx, hy, self.omega, nu, self.shift)
 
     def residual_norm(self, u, rhs, level=0):
         hx, hy = self.h[level]
-        return float(l2_norm(var_residual(u, rhs, self.a[level], hx, hy, self.coeff), hx, hy))
+        return float(l2_norm(var_residual(u, rhs, self.a[level], hx, hy, self.coeff, self.shift), hx, hy))
 
     def cycle_once(self, u, level=0, pm=None):
         L = len(self.shapes)
@@ -479,12 +482,12 @@ class VarMGOracle(MGOracle):
         if level == L - 1:
             u = u.copy()
             for it in range(1, self.cmaxit + 1):
-                var_lexgs_sweep(u, self.rhs[level], self.a[level], hx, hy)
-                if l2_norm(var_coarse_residual(u, self.rhs[level], self.a[level], hx, hy, self.coeff), hx, hy) < self.ctol:
+                var_lexgs_sweep(u, self.rhs[level], self.a[level], hx, hy, self.shift)
+                if l2_norm(var_coarse_residual(u, self.rhs[level], self.a[level], hx, hy, self.coeff, self.shift), hx, hy) < self.ctol:
                     break
             return u
         u = self._smooth(u, level, self.pre)
-        r = var_residual(u, self.rhs[level], self.a[level], hx, hy, self.coeff)
+        r = var_residual(u, self.rhs[level], self.a[level], hx, hy, self.coeff, self.shift)
         self.rhs[level + 1] = restrict_fw(r, self.dtype).copy()
         e = np.zeros_like(self.rhs[level + 1])
         reps = 1 if self.cycle == "V" else 2 if self.cycle == "W" else max(1, 2 ** (L - level - 2))

@@ -22,6 +22,7 @@ import numpy as np
 
 REF = os.environ.get("MG_REFERENCE_SRC", "/root/reference/src")
 sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.dont_write_bytecode = True
 logging.disable(logging.CRITICAL)
 
@@ -205,8 +206,44 @@ def gen_large():
     print(f"  1025^2: {info['iterations']} cycles, {dt / info['iterations']:.2f} s/cycle (reference CPU path, 1 core)")
 
 
+from heat_inputs import heat_cases, heat_config                          # noqa: E402  (tests/golden/heat_inputs.py)
+
+
+def gen_heat():
+    """applications/heat_equation.py run as is: a few fixed-dt steps per scheme (the implicit ones are the reference's
+    100 Gauss-Seidel sweeps per step), plus one adaptive Crank-Nicolson integration."""
+    from multigrid.applications import heat_equation as ref_heat
+    out = {}
+    for name, (n, alpha, scheme, dt, steps, bc_kind, with_source) in heat_cases().items():
+        g = Grid(n, n)
+        hs = ref_heat.HeatEquationSolver(heat_config(ref_heat, alpha, bc_kind, with_source), g)
+        u = hs.set_initial_condition().copy()
+        out[f"{name}__u0"] = u.copy()
+        sch = ref_heat.TimeSteppingScheme(scheme)
+        if dt is None:
+            dt = 0.2 * g.hx**2 / alpha if scheme == "explicit_euler" else 0.1 * g.hx
+        for k in range(steps):
+            u = hs._single_time_step(u, dt, sch)
+            hs.current_time += dt
+            out[f"{name}__u{k + 1}"] = u.copy()
+        out[f"{name}__dt"] = np.array(dt)
+    # adaptive step doubling, Crank-Nicolson, 17^2
+    g = Grid(17, 17)
+    hs = ref_heat.HeatEquationSolver(heat_config(ref_heat, 1.0, "zero", False), g)
+    hs.set_initial_condition()
+    res = hs.solve_time_dependent(t_final=0.02, dt_initial=0.004, scheme=ref_heat.TimeSteppingScheme.CRANK_NICOLSON,
+                                  adaptive=True, error_tolerance=2e-3)
+    out["adaptive17__final"] = res["final_solution"]
+    out["adaptive17__times"] = np.array(res["time_history"])
+    out["adaptive17__dts"] = np.array(res["dt_history"])
+    out["adaptive17__steps"] = np.array(res["total_steps"])
+    save("heat.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "solves", "large"]
+    which = sys.argv[1:] or ["ops", "solves", "large", "heat"]
+    if "heat" in which:
+        gen_heat()
     if "ops" in which:
         gen_ops()
     if "solves" in which:
