@@ -1108,6 +1108,18 @@ constexpr int kFusedBlock = 512;
 #ifndef MG_FUSED_TI
 #define MG_FUSED_TI 32
 #endif
+// Profiling experiments (timing-only builds, results are wrong): MG_EXP_NO_LOAD drops the global loads of the fused
+// legs, MG_EXP_NO_COMPUTE their LDS stages, MG_EXP_NO_STORE their global stores -- how much of a leg is memory phase,
+// how much compute, how much overlaps (profiles/README.md, round-1 experiment table).
+#ifndef MG_EXP_NO_LOAD
+#define MG_EXP_NO_LOAD 0
+#endif
+#ifndef MG_EXP_NO_COMPUTE
+#define MG_EXP_NO_COMPUTE 0
+#endif
+#ifndef MG_EXP_NO_STORE
+#define MG_EXP_NO_STORE 0
+#endif
 constexpr int kFusedTI = MG_FUSED_TI;      // tile rows of the fused legs (even: coarse rows sit on every other tile row)
 constexpr int kPostNone = 0, kPostRestrict = 1, kPostNorm = 2;
 
@@ -1177,7 +1189,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
     if (!worker || r >= S::RI) continue;
     const bool in_dom = gi >= 0 && gi < a.nx && gj0 >= 0 && gj0 < a.nyv;
     Pack<T> uu = zero_pack<T>();
-    if (in_dom) {
+    if (in_dom && !MG_EXP_NO_LOAD) {
       f[k] = ldg(rhs + (size_t)gi * a.ld + gj0);
       if (!ZERO_INIT) uu = ldg(u + (size_t)gi * a.ld + gj0);
       if (PROLONG) {
@@ -1232,7 +1244,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
       __syncthreads();
     }
   } else
-  for (int s = 0; s < a.nsweep; ++s) {
+  for (int s = 0; s < (MG_EXP_NO_COMPUTE ? 0 : a.nsweep); ++s) {
     if (worker && r_base < S::RI) {
       Pack<T> up = (r_base >= 1) ? *reinterpret_cast<const Pack<T>*>(src + (r_base - 1) * S::RJ + lc) : zero_pack<T>();
       Pack<T> mid = *reinterpret_cast<const Pack<T>*>(src + r_base * S::RJ + lc);
@@ -1271,7 +1283,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   for (int k = 0; k < S::RPT; ++k) {
     const int r = r_base + k, gi = ri0 + r;
     if (!worker || r >= S::RI) continue;
-    if (r >= HALO && r < HALO + kFusedTI && cv >= S::HV && cv < S::HV + S::TJ / N && gi < a.nx && gj0 < a.nyv)
+    if (!MG_EXP_NO_STORE && r >= HALO && r < HALO + kFusedTI && cv >= S::HV && cv < S::HV + S::TJ / N && gi < a.nx && gj0 < a.nyv)
       stg(out + (size_t)gi * a.ld + gj0, *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc));
   }
 
@@ -1290,7 +1302,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
       Pack<T> o = f[k];
       const bool in_tile = r >= HALO && r < HALO + kFusedTI && cv >= S::HV && cv < S::HV + S::TJ / N;
       const bool wanted = (POST == kPostRestrict) || in_tile;      // the norm only needs r on the tile itself
-      if (wanted && r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+      if (!MG_EXP_NO_COMPUTE && wanted && r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
         const T left = src[r * S::RJ + lc - 1];
         const T right = src[r * S::RJ + lc + N];
 #pragma unroll
@@ -1329,6 +1341,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
     const T* p = dst + (fi - ri0) * S::RJ + (fj - rj0);
     const T corners = ((p[-S::RJ - 1] + p[-S::RJ + 1]) + p[S::RJ - 1]) + p[S::RJ + 1];
     const T edges = ((p[-S::RJ] + p[S::RJ]) + p[-1]) + p[1];
+    if (MG_EXP_NO_STORE) { if (corners == T(12345.678)) rhs_coarse[0] = (TX)edges; continue; }
     rhs_coarse[(size_t)ic * a.ldc + jc] = (TX)((T(1.0 / 16.0) * corners + T(1.0 / 8.0) * edges) + T(1.0 / 4.0) * p[0]);
   }
 }
