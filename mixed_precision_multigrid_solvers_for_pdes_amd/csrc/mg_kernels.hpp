@@ -1181,28 +1181,49 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   const int r_base = rg * S::RPT;
 
   // ---- load: rhs strip into registers, u (+ P e) into LDS --------------------------------------
-  Pack<T> f[S::RPT];
+  // PROLONG: the (RI/2 + 2) x (RJ/2 + 2) patch of coarse values under the region is staged once, coalesced, in
+  // bufB (free until the first sweep writes it); the interpolation then reads LDS instead of issuing 2 (N/2 + 1)
+  // scalar global loads per row vector and thread -- three times the load instructions of u and rhs together.
+  constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
+  static_assert(!PROLONG || (size_t)PH * PW * sizeof(TX) <= sizeof(T) * S::ELEMS, "coarse patch does not fit the LDS buffer");
+  const int pic0 = (ri0 >> 1) + a.ci_off, pjc0 = (rj0 >> 1) + a.cj_off;     // coarse cell of patch entry (0, 0)
+  TX* patch = reinterpret_cast<TX*>(bufB);
+  if (PROLONG && !MG_EXP_NO_LOAD) {
+    for (int idx = threadIdx.x; idx < PH * PW; idx += kFusedBlock) {
+      const int pr = idx / PW, pc = idx - pr * PW;
+      const int ic = pic0 + pr, jc = pjc0 + pc;
+      patch[idx] = (ic >= 0 && ic < a.nxc && jc >= 0 && jc < a.nyc) ? e_coarse[(size_t)ic * a.ldc + jc] : TX(0);
+    }
+  }
+  Pack<T> f[S::RPT], uu[S::RPT];
 #pragma unroll
   for (int k = 0; k < S::RPT; ++k) {
     const int r = r_base + k, gi = ri0 + r;
     f[k] = zero_pack<T>();
+    uu[k] = zero_pack<T>();
     if (!worker || r >= S::RI) continue;
-    const bool in_dom = gi >= 0 && gi < a.nx && gj0 >= 0 && gj0 < a.nyv;
-    Pack<T> uu = zero_pack<T>();
-    if (in_dom && !MG_EXP_NO_LOAD) {
+    if (gi >= 0 && gi < a.nx && gj0 >= 0 && gj0 < a.nyv && !MG_EXP_NO_LOAD) {
       f[k] = ldg(rhs + (size_t)gi * a.ld + gj0);
-      if (!ZERO_INIT) uu = ldg(u + (size_t)gi * a.ld + gj0);
-      if (PROLONG) {
-        using TS = typename std::conditional<(sizeof(TC) > sizeof(T)), TC, T>::type;
-        TC val[N];
-        bool ok[N];
-        prolong_vec<TX, TC, N>(e_coarse, a.ldc, a.nxc, a.nyc, gi, gj0, a.nx, a.ny, a.sides, val, ok, a.ci_off, a.cj_off);
-#pragma unroll
-        for (int e = 0; e < N; ++e)
-          if (ok[e]) uu.v[e] = (T)((TS)uu.v[e] + (TS)val[e]);
-      }
+      if (!ZERO_INIT) uu[k] = ldg(u + (size_t)gi * a.ld + gj0);
     }
-    *reinterpret_cast<Pack<T>*>(bufA + r * S::RJ + lc) = uu;
+  }
+  if (PROLONG) __syncthreads();
+#pragma unroll
+  for (int k = 0; k < S::RPT; ++k) {
+    const int r = r_base + k, gi = ri0 + r;
+    if (!worker || r >= S::RI) continue;
+    if (PROLONG && gi >= 0 && gi < a.nx && gj0 >= 0 && gj0 < a.nyv && !MG_EXP_NO_LOAD) {
+      using TS = typename std::conditional<(sizeof(TC) > sizeof(T)), TC, T>::type;
+      TC val[N];
+      bool ok[N];
+      // the patch addressed like the coarse array: entry (ic, jc) at pe[ic * PW + jc]
+      const TX* pe = patch - ((ptrdiff_t)pic0 * PW + pjc0);
+      prolong_vec<TX, TC, N>(pe, PW, a.nxc, a.nyc, gi, gj0, a.nx, a.ny, a.sides, val, ok, a.ci_off, a.cj_off);
+#pragma unroll
+      for (int e = 0; e < N; ++e)
+        if (ok[e]) uu[k].v[e] = (T)((TS)uu[k].v[e] + (TS)val[e]);
+    }
+    *reinterpret_cast<Pack<T>*>(bufA + r * S::RJ + lc) = uu[k];
   }
   __syncthreads();
 
