@@ -37,7 +37,9 @@ def cpu_baseline(n, levels, seconds_budget=15.0):
     rhs = O.sine_rhs(n, n)
     try:
         from oracle.c_oracle import COracle
-        co = COracle(n, n, max_levels=levels, cycle="V", smoother="jacobi", omega=0.8)
+        # one GPU's share of the host: at most 16 threads (a 128-thread team on the shared box runs 3x SLOWER)
+        share = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+        co = COracle(n, n, max_levels=levels, cycle="V", smoother="jacobi", omega=0.8, threads=share)
         co.set_problem(rhs)
         co.cycle()                                   # warm-up (page faults, thread pool)
         cycles, t0 = 0, time.time()

@@ -26,8 +26,10 @@ def load():
 
 class COracle:
     def __init__(self, nx, ny, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0, max_levels=4, cycle="V", pre=2, post=2,
-                 smoother="jacobi", omega=0.8, coarse_tol=1e-12, coarse_maxit=1000):
+                 smoother="jacobi", omega=0.8, coarse_tol=1e-12, coarse_maxit=1000, threads=None):
         self.lib = load()
+        if threads:
+            self.lib.mgo_set_threads(int(threads))
         self.nx, self.ny = nx, ny
         self.h = self.lib.mgo_create(nx, ny, *map(float, domain), float(coeff), max_levels, {"V": 0, "W": 1, "F": 2}[cycle],
                                      pre, post, {"jacobi": 0, "rbgs": 1}[smoother], float(omega), float(coarse_tol), coarse_maxit)

@@ -31,6 +31,15 @@ int mgo_threads(void) {
 #endif
 }
 
+/* cap the OpenMP team (bench.py: the GPU box grants one GPU's share of the host cores, not all of them) */
+void mgo_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 void mgo_jacobi(const double* u, const double* f, double* out, int nx, int ny, double hx, double hy, double omega) {
   const double hx2_inv = 1.0 / (hx * hx), hy2_inv = 1.0 / (hy * hy);
   const double diag = -(2.0 * hx2_inv + 2.0 * hy2_inv);
