@@ -29,7 +29,7 @@ def sine_rhs(nx, ny, dtype=np.float64):
     return (2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * y)[None, :]).astype(dtype)
 
 
-def cpu_baseline(n, levels, seconds_budget=15.0):
+def cpu_baseline(n, levels, seconds_budget=12.0):
     """The oracle timed on this host on a bounded sample of the same workload: whole V(2,2) Jacobi cycles at n^2 in
     fp64.  Preferred: the C restatement (oracle/mg_oracle.c, OpenMP over all host cores it is given); fallback: the
     NumPy restatement on one core.  Both reproduce the reference's CPU arithmetic (tests/test_oracle_golden.py)."""
@@ -47,7 +47,7 @@ def cpu_baseline(n, levels, seconds_budget=15.0):
             co.cycle()
             cycles += 1
             el = time.time() - t0
-            if el > seconds_budget or cycles >= 40:
+            if el > seconds_budget or cycles >= 2000:
                 break
         threads = co.threads
         co.close()
