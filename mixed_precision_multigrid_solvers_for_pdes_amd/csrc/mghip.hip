@@ -48,7 +48,6 @@ inline int pitch_elems(int dt, int ny) {
   return (int)(bytes / esize(dt));
 }
 
-constexpr int kMaxPartials = 1 << 16;   // upper bound on blocks that emit a partial sum
 
 template <typename T>
 mg::TileGeom make_geom(int nx, int ny, int ld, bool interior_only) {
@@ -480,7 +479,7 @@ struct mg_handle {
   std::vector<Level> lv;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;   // created by mg_create; `stream` may be redirected by mg_set_stream
-  double* partials = nullptr;   // device, kMaxPartials doubles
+  double* partials = nullptr;   // device: one fp64 partial per workgroup of the largest reduction (sized in mg_create)
   double* d_scalar = nullptr;   // device, one double
   int* d_int = nullptr;         // device, one int (coarse sweeps)
   double* h_scalar = nullptr;   // pinned host
@@ -1118,7 +1117,12 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
       }
     }
   }
-  if ((rc = alloc_zero(&h->err, (void**)&h->partials, sizeof(double) * kMaxPartials, h->stream)) != MG_OK) return bail(rc);
+  {
+    // fp64 tiles are the narrowest (32 x 64 cells): their count bounds every per-workgroup partial sum on level 0
+    const long long tiles = make_geom<double>(cfg->nx, cfg->ny, pitch_elems(MG_F64, cfg->ny), false).ntiles;
+    if ((rc = alloc_zero(&h->err, (void**)&h->partials, sizeof(double) * (size_t)std::max<long long>(2048, tiles), h->stream)) != MG_OK)
+      return bail(rc);
+  }
   if ((rc = alloc_zero(&h->err, (void**)&h->d_scalar, sizeof(double), h->stream)) != MG_OK) return bail(rc);
   if ((rc = alloc_zero(&h->err, (void**)&h->d_int, sizeof(int), h->stream)) != MG_OK) return bail(rc);
   if ((rc = alloc_zero(&h->err, &h->staging, (size_t)cfg->nx * pitch_elems(MG_F64, cfg->ny) * 8, h->stream)) != MG_OK) return bail(rc);
@@ -1129,10 +1133,6 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
     h->mbox->value = 0; h->mbox->seq = 0;
   } else {
     h->mbox_dev = nullptr;     // no mapped host memory: fall back to copy + stream synchronisation
-  }
-  {
-    const mg::TileGeom g = make_geom<double>(cfg->nx, cfg->ny, h->lv[0].ld[1], false);
-    if (g.ntiles > kMaxPartials) { h->err = "grid too large for the partial-sum buffer"; return bail(MG_ERR_INVALID_VALUE); }
   }
   if ((rc = plan_tail(h)) != MG_OK) return bail(rc);
   if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MG_ERR_HIP); }

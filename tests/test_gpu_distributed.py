@@ -53,3 +53,44 @@ def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cy
     s.close()
     np.testing.assert_array_equal(u, u_ref)
     np.testing.assert_allclose(hist, ref_hist, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name,px,py,NX,NY,dtype,cyc,kind,omega,mode", [
+    # BASELINE config 4: 8193^2 fp32 on 2 x 2 GPUs (4097^2 + ghost zone each), V(2,2) weighted Jacobi
+    ("config4", 2, 2, 8193, 8193, "managed32", "V", "jacobi", 0.8, "fused"),
+    # BASELINE config 5's decomposition and cycle: 16385^2, W(2,2) red-black GS, 2 x 4 blocks of 8193 x 4097
+    # (fp64 here: the distributed driver runs one precision on its distributed levels)
+    ("config5", 2, 4, 16385, 16385, np.float64, "W", "rbgs", 1.0, "per_operator"),
+])
+def test_full_size_configs_as_virtual_ranks(name, px, py, NX, NY, dtype, cyc, kind, omega, mode):
+    """The multi-GPU configurations of BASELINE.json at their full sizes, all ranks as virtual ranks on ONE GPU
+    (288 GB of HBM hold them): the decomposed cycle must equal the single-domain engine bit for bit."""
+    import torch
+    managed = dtype == "managed32"
+    dtype = np.float32 if managed else dtype
+    rng = np.random.default_rng(7)
+    rhs = rng.standard_normal((NX, NY), dtype=np.float32).astype(dtype, copy=False)
+    u0 = None
+    levels = mg.default_max_levels(NX, NY)
+    prec = _lib.MG_PREC_SINGLE_MANAGED if managed else _lib.MG_PREC_DOUBLE
+    eng = mg.MultigridEngine(NX, NY, max_levels=levels, cycle=cyc, smoother=_lib.MG_JACOBI if kind == "jacobi" else _lib.MG_RBGS,
+                             omega=omega, precision=prec)
+    eng.set_rhs(rhs); eng.set_solution(None)
+    ref_hist = []
+    for _ in range(2):
+        eng.cycle(1); ref_hist.append(eng.residual_norm())
+    u_ref = eng.get_solution(dtype)
+    eng.close()
+    ops = D.HipOps(dtype, torch.device("cuda", 0), managed_single=managed)
+    s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle=cyc, smoother=kind,
+                               omega=omega, mode=mode)
+    assert s.mode == mode and s.Ld >= 3
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], u0)
+    hist = []
+    for _ in range(2):
+        s.cycle(0); hist.append(s.residual_norm())
+    u = H.assemble(s, NX, NY, dtype)
+    s.close()
+    assert ref_hist[1] < ref_hist[0]
+    np.testing.assert_allclose(hist, ref_hist, rtol=1e-12)
+    assert np.array_equal(u, u_ref)
