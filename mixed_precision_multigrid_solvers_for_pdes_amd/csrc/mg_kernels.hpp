@@ -330,14 +330,24 @@ struct HostMailbox {
   unsigned long long seq;
 };
 
-// Fixed-order final reduction of the per-block partials (deterministic, one block).
-__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials, int n,
-                                                                 double* __restrict__ out, HostMailbox* mailbox,
-                                                                 unsigned long long seq) {
-  __shared__ double red[kBlock / 64];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += kBlock) acc += partials[i];
-  const double t = block_reduce_sum(acc, red);
+// Fixed-order final reduction of the per-block partials (deterministic, one block).  It sits between two cycles on
+// the stream, so it is built for latency: 1024 threads, four independent 16-byte loads in flight per thread.
+constexpr int kReduceBlock = 1024;
+__global__ __launch_bounds__(kReduceBlock) void reduce_partials_kernel(const double* __restrict__ partials, int n,
+                                                                       double* __restrict__ out, HostMailbox* mailbox,
+                                                                       unsigned long long seq) {
+  __shared__ double red[kReduceBlock / 64];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const int nv = n >> 1;                                  // whole double2 vectors (the buffer is 16-byte aligned)
+  const Pack<double>* pv = reinterpret_cast<const Pack<double>*>(partials);
+  int i = threadIdx.x;
+  for (; i + 3 * kReduceBlock < nv; i += 4 * kReduceBlock) {
+    const Pack<double> x0 = pv[i], x1 = pv[i + kReduceBlock], x2 = pv[i + 2 * kReduceBlock], x3 = pv[i + 3 * kReduceBlock];
+    a0 += x0.v[0] + x0.v[1]; a1 += x1.v[0] + x1.v[1]; a2 += x2.v[0] + x2.v[1]; a3 += x3.v[0] + x3.v[1];
+  }
+  for (; i < nv; i += kReduceBlock) { const Pack<double> x = pv[i]; a0 += x.v[0] + x.v[1]; }
+  if ((n & 1) && threadIdx.x == 0) a1 += partials[n - 1];
+  const double t = block_reduce_sum<kReduceBlock / 64>((a0 + a1) + (a2 + a3), red);
   if (threadIdx.x == 0) {
     *out = t;
     if (mailbox) {

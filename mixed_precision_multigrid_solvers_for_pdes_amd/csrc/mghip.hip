@@ -138,7 +138,7 @@ int launch_sumsq(const void* x, double* partials, int ld, int i_lo, int i_hi, in
 
 inline void launch_reduce(const double* partials, int n, double* out, hipStream_t st, mg::HostMailbox* mailbox = nullptr,
                           unsigned long long seq = 0) {
-  hipLaunchKernelGGL(mg::reduce_partials_kernel, dim3(1), dim3(mg::kBlock), 0, st, partials, n, out, mailbox, seq);
+  hipLaunchKernelGGL(mg::reduce_partials_kernel, dim3(1), dim3(mg::kReduceBlock), 0, st, partials, n, out, mailbox, seq);
 }
 
 template <typename TI, typename TO>
