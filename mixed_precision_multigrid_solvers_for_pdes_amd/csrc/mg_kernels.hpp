@@ -221,10 +221,35 @@ __global__ __launch_bounds__(kBlock) void rbgs_colour_kernel(T* __restrict__ u, 
 //   WRITE_R: store r (3 words/DoF) ; NORM: also emit one fp64 partial sum of r^2 per block
 //   (wave64 shuffle reduction, then 4 waves through LDS) -> ||r||^2 needs no second pass over r.
 // --------------------------------------------------------------------------------------------
+// Sum over the wave, valid in lane 0.  The tree is x[l] += x[l + off] for off = 32, 16, 8, 4, 2, 1 -- what a
+// __shfl_down loop computes -- but without its six dependent ds_bpermute round trips (~130 cycles each, twice per
+// double): the two cross-row steps are gfx950's v_permlane32_swap / v_permlane16_swap, the four in-row steps DPP
+// row_shl.  The coarsest-level stop test runs this once per Gauss-Seidel sweep, ~40 times per cycle.
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_move(double x) {
+  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true),
+                          __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ double wave_reduce_sum(double x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  {   // lanes 0..31 += lanes 32..63   (swap: lanes [32:63] of the first operand <-> lanes [0:31] of the second)
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    x += __hiloint2double(__builtin_amdgcn_permlane32_swap(hi, hi, false, false)[1],
+                          __builtin_amdgcn_permlane32_swap(lo, lo, false, false)[1]);
+  }
+  {   // rows 0 / 2 += rows 1 / 3        (swap: odd rows of the first operand <-> even rows of the second)
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    x += __hiloint2double(__builtin_amdgcn_permlane16_swap(hi, hi, false, false)[1],
+                          __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[1]);
+  }
+  x += dpp_row_move<0x108>(x);      // row_shl:8
+  x += dpp_row_move<0x104>(x);      // row_shl:4
+  x += dpp_row_move<0x102>(x);      // row_shl:2
+  x += dpp_row_move<0x101>(x);      // row_shl:1
   return x;
+}
+// lane 0's value in every lane (v_readfirstlane: all lanes are active where this is used)
+__device__ __forceinline__ double wave_first(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 
 // Sum over the block of NW waves; result valid in thread 0.  `red` is >= NW doubles of LDS.
@@ -583,7 +608,7 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
     }
   }
   ring = wave_reduce_sum(ring);
-  ring = __shfl(ring, 0, 64);
+  ring = wave_first(ring);
   wave_lds_fence<T>();
   int sweeps = maxit;
   if (ncell <= 64) {
@@ -624,7 +649,7 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
           acc = (double)rv * (double)rv;
         }
         acc = wave_reduce_sum(acc);
-        acc = __shfl(acc, 0, 64);
+        acc = wave_first(acc);
         if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
           if (c < ncell) su[c] = snap[c];
           sweeps = kc;
@@ -668,7 +693,7 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
         acc += (double)rv * (double)rv;
       }
       acc = wave_reduce_sum(acc);
-      acc = __shfl(acc, 0, 64);
+      acc = wave_first(acc);
       if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
         for (int c = lane; c < ncell; c += 64) su[c] = snap[c];
         sweeps = kc;
@@ -740,7 +765,7 @@ __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ 
       acc += (double)rv * (double)rv;
     }
     acc = wave_reduce_sum(acc);
-    acc = __shfl(acc, 0, 64);
+    acc = wave_first(acc);
     if (sqrt(hxhy * acc) < tol) break;
   }
   __syncthreads();
@@ -908,11 +933,21 @@ __device__ __forceinline__ void tail_rb_pass(T* __restrict__ u, const T* __restr
   }
 }
 
+#ifndef MG_EXP_TAIL_TRACE
+#define MG_EXP_TAIL_TRACE 0
+#endif
+#if MG_EXP_TAIL_TRACE
+__device__ long long g_tail_trace[64];     // timing experiment: s_memtime at entry, after the prologue, after every op, at exit
+#define TAIL_STAMP(k) do { if (threadIdx.x == 0 && (k) < 64) g_tail_trace[k] = clock64(); } while (0)
+#else
+#define TAIL_STAMP(k) do { } while (0)
+#endif
 template <typename T, typename TCO, typename TC>
 __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __restrict__ rhs_top, T* __restrict__ u_top,
                                                                  const int* __restrict__ ops, TailArgs a, int zero_top,
                                                                  int* __restrict__ sweeps_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pool[];
+  TAIL_STAMP(0);
   const int last = a.nlev - 1;
   const T omega = (T)a.omega, one_m_omega = (T)(1.0 - a.omega), coeff = (T)a.coeff;
   // per level: two iterate buffers (ping-pong) and the rhs; the last level holds {u, rhs} in TCO
@@ -940,7 +975,9 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
   __syncthreads();
 
   unsigned cur = 0;   // bit l: which iterate buffer of level l is current
+  TAIL_STAMP(1);
   for (int ip = 0; ip < a.nops; ++ip) {
+    if (ip > 0) TAIL_STAMP(1 + ip);
     const int op = ops[ip];
     const int code = op & 0xff, l = (op >> 8) & 0xff, zflag = (op >> 16) & 0xff;
     const bool zero = (zflag == 2) ? (zero_top != 0) : (zflag != 0);
@@ -1039,7 +1076,7 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
             acc += (double)rv * (double)rv;
           }
           acc = wave_reduce_sum(acc);
-          acc = __shfl(acc, 0, 64);
+          acc = wave_first(acc);
           if (sqrt(L.hxhy * acc) < a.tol) break;
         }
         if (lane == 0 && sweeps_out) *sweeps_out = (it > a.maxit) ? a.maxit : it;
@@ -1083,6 +1120,7 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
       }
     }
   }
+  TAIL_STAMP(1 + a.nops);
   {   // the correction of the top level back to HBM (interior cells; the ring is zero and stays zero there)
     const TailLevel& L0 = a.lv[0];
     const T* u0 = Ubuf(0, cur & 1);
@@ -1091,6 +1129,7 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
       if (i >= 1 && i < L0.nx - 1 && j >= 1 && j < L0.ny - 1) u_top[(size_t)i * a.ld_top + j] = u0[c];
     }
   }
+  TAIL_STAMP(2 + a.nops);
 }
 
 // ============================================================================================

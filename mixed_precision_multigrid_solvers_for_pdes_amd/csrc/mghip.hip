@@ -1258,6 +1258,13 @@ int mg_set_coefficient(mg_handle* h, const void* a_host, int host_dtype) {
   return MG_OK;
 }
 
+#if MG_EXP_TAIL_TRACE
+// timing experiment: s_memtime stamps of the last coarse_tail_kernel launch (entry, prologue, after every op, exit)
+int mg_exp_tail_trace(long long* out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(mg::g_tail_trace), sizeof(long long) * 64) == hipSuccess ? MG_OK : MG_ERR_HIP;
+}
+#endif
+
 int mg_set_shift(mg_handle* h, double sigma) {
   if (!h || !(sigma >= 0.0) || !std::isfinite(sigma))
     return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_shift: sigma must be finite and >= 0");
