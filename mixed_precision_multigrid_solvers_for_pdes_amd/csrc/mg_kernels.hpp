@@ -592,10 +592,91 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+template <int CTRL> __device__ __forceinline__ float dpp_row_move(float x) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// The 5 x 5 coarsest grid (3 x 3 unknowns -- the end of every hierarchy of 2^k + 1 grids): the same pipelined sweeps
+// with the nine unknowns in lanes 0..8 and NO LDS traffic in the loop.  Neighbours come from lanes c -+ 1, c -+ 3 by
+// DPP row shifts (ring neighbours are per-lane constants); a lane keeps its last three sweep values in a shift
+// register, and because a lane on diagonal d is always floor((6 - d) / 2) sweeps ahead of the sweep under test, the
+// snapshot the stop test needs sits at a per-lane constant depth.  Same expressions, same sweep / stop semantics as
+// the LDS version below (the stop test sums its nine squares in a different lane order).
+template <typename T>
+__device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf, T hx2, T hy2, T diag, T coeff, T omega,
+                                   T one_m_omega, bool exact, double hxhy, double tol, int maxit, int lane) {
+  constexpr int ny = 5;
+  const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
+  double ring = 0.0;
+  if (lane < 25) {
+    const int i = lane / ny, j = lane - i * ny;
+    if (i == 0 || i == 4 || j == 0 || j == 4) ring = (double)sf[lane] * (double)sf[lane];
+  }
+  ring = wave_first(wave_reduce_sum(ring));
+  const bool mine = lane < 9;
+  const int ci = mine ? lane / 3 : 0, cj = mine ? lane - 3 * (lane / 3) : 0;
+  const int gi = ci + 1, gj = cj + 1, g = gi * ny + gj, d = gi + gj;
+  const T fv = mine ? sf[g] : T(0);
+  T uv = mine ? su[g] : T(0);
+  // ring neighbours (constant over the solve); interior neighbours are fetched from the adjacent lanes every step
+  const bool up_ring = gi == 1, dn_ring = gi == 3, lf_ring = gj == 1, rt_ring = gj == 3;
+  const T up_c = su[g - ny], dn_c = su[g + ny], lf_c = su[g - 1], rt_c = su[g + 1];
+  T h0 = uv, h1 = uv, h2 = uv;                    // the lane's last three sweep values, newest first
+  int tnext = 2 + d, knext = 1;
+  int kc = 1, tdone = 2 + 6;
+  const int lead = (6 - d) >> 1;                  // sweeps this lane is ahead of the sweep under test
+  int sweeps = maxit;
+  T result = uv;
+  for (int t = 4;; ++t) {
+    {
+      // the four moves run with EVERY lane active (a DPP read of a lane that is masked off returns 0), the choice
+      // between ring constant and neighbour comes afterwards
+      const T n_up = dpp_row_move<0x113>(uv);     // row_shr:3  (lane c - 3)
+      const T n_dn = dpp_row_move<0x103>(uv);     // row_shl:3  (lane c + 3)
+      const T n_lf = dpp_row_move<0x111>(uv);     // row_shr:1
+      const T n_rt = dpp_row_move<0x101>(uv);     // row_shl:1
+      const T up = up_ring ? up_c : n_up, dn = dn_ring ? dn_c : n_dn, lf = lf_ring ? lf_c : n_lf, rt = rt_ring ? rt_c : n_rt;
+      const T sx = dn + up, sy = rt + lf;
+      const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
+      const T num = fv + nb;
+      const T un = exact ? num * rdiag : num / diag;
+      const T nv = one_m_omega * uv + omega * un;
+      if (mine && t == tnext && knext <= maxit) {
+        uv = nv;
+        h2 = h1; h1 = h0; h0 = nv;
+        tnext += 2;
+        ++knext;
+      }
+    }
+    if (t == tdone) {
+      const int depth = min(lead, maxit - kc);
+      const T snap = depth == 0 ? h0 : (depth == 1 ? h1 : h2);
+      const T n_up = dpp_row_move<0x113>(snap), n_dn = dpp_row_move<0x103>(snap);
+      const T n_lf = dpp_row_move<0x111>(snap), n_rt = dpp_row_move<0x101>(snap);
+      const T up = up_ring ? up_c : n_up, dn = dn_ring ? dn_c : n_dn, lf = lf_ring ? lf_c : n_lf, rt = rt_ring ? rt_c : n_rt;
+      const T sx = dn + up, sy = rt + lf;
+      const T rv = fv - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap * diag);
+      double acc = mine ? (double)rv * (double)rv : 0.0;
+      acc = wave_first(wave_reduce_sum(acc));
+      if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
+        result = snap;
+        sweeps = kc;
+        break;
+      }
+      ++kc;
+      tdone += 2;
+    }
+  }
+  if (mine) su[g] = result;
+  wave_lds_fence<T>();
+  return sweeps;
+}
+
 template <typename T>
 __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* __restrict__ hist, int nx, int ny,
                                T hx2, T hy2, T diag, T coeff, T omega, T one_m_omega, bool exact, double hxhy,
                                double tol, int maxit, int lane) {
+  if (nx == 5 && ny == 5) return lexgs_pipelined_5x5<T>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, exact, hxhy, tol, maxit, lane);
   const int ncell = nx * ny, dmax = nx + ny - 4;
   const int H = (dmax - 1) / 2 + 2;
   const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
