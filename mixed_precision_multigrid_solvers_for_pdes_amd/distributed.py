@@ -615,6 +615,16 @@ class DistributedMultigrid:
                 tmp.copy_(d.u[0])
         return math.sqrt(hx * hy * self.allreduce_sum(parts))
 
+    def take_iterate_from(self, other):
+        """The fine iterate of `other` (same decomposition, another working precision) becomes this solver's iterate:
+        the on-device cast of PrecisionManager.convert_array (core/precision.py:106-134), ghost zone included."""
+        for r, d in self.doms.items():
+            b = d.blk[0]
+            d.u[0][:b.lnx, :b.lny].copy_(other.doms[r].u[0][:b.lnx, :b.lny])      # torch casts on the device; pitches differ
+            if d.t[0] is not None:
+                d.t[0].copy_(d.u[0])
+        self._last_norm_parts = None
+
     def local_solution(self, rank):
         d = self.doms[rank]
         b = d.blk[0]
@@ -637,6 +647,10 @@ def sine_rhs_block(b, domain=(0.0, 1.0, 0.0, 1.0)):
 # bench.py --gpus N (N > 1): weak scaling, 4097^2 points per GPU
 # ------------------------------------------------------------------------------------------------
 def bench_main(args, rank, local_rank, world):
+    """bench.py --gpus N (N > 1): BASELINE config 3's workload per GPU (4097^2, adaptive fp32 -> fp64, V(2,2) weighted
+    Jacobi) on a px x py block decomposition -- weak scaling of the N = 1 bench line.  The precision policy is the
+    engine's (core/precision.py:270-302 with the one-way promotion): start in double, drop to single while
+    ||r|| > 100 thr, promote for good once ||r|| < 10 thr; it switches between two solvers that share the decomposition."""
     import torch
     import torch.distributed as dist
     assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
@@ -654,62 +668,103 @@ def bench_main(args, rank, local_rank, world):
     NX, NY = px * m + 1, py * m + 1
     # unit cells: the domain grows with the process grid so that hx = hy = 1/(n-1) as on one GPU
     domain = (0.0, float(px), 0.0, float(py))
-    ops = HipOps(np.float32, torch.device("cuda", local_rank), managed_single=True)
-    solver = DistributedMultigrid(NX, NY, px, py, [rank], ops, dist, domain=domain, smoother="jacobi", omega=0.8,
-                                  cycle="V", pre=2, post=2)
-    solver.set_problem(lambda b: sine_rhs_block(b, domain))
+    dev = torch.device("cuda", local_rank)
+    thr = 1e-6                                                    # BASELINE config 3: switch_threshold
+    solvers = {}
+    for name, ops in (("f32", HipOps(np.float32, dev, managed_single=True)), ("f64", HipOps(np.float64, dev))):
+        solvers[name] = DistributedMultigrid(NX, NY, px, py, [rank], ops, dist, domain=domain, smoother="jacobi", omega=0.8,
+                                             cycle="V", pre=2, post=2)
+
+    def reset():
+        for sv in solvers.values():
+            sv.set_problem(lambda b: sine_rhs_block(b, domain))
+        return "f64", False, solvers["f64"].residual_norm()
+
+    def step(phase, promoted, rn):
+        """policy check (before the cycle, solvers/multigrid.py:224-227) -> cycle -> norm"""
+        want = phase
+        if phase == "f64" and not promoted and rn > 100.0 * thr:
+            want = "f32"
+        elif phase == "f32" and rn < 10.0 * thr:
+            want, promoted = "f64", True
+        if want != phase:
+            solvers[want].take_iterate_from(solvers[phase])
+            phase = want
+        solvers[phase].cycle(0)
+        return phase, promoted, solvers[phase].residual_norm()
+
     K, W = args.steps, args.warmup
+    phase, promoted, rn = reset()
     for _ in range(W):
-        solver.cycle(0)
-        solver.residual_norm()
-    solver.set_problem(lambda b: sine_rhs_block(b, domain))
-    hist = []
+        phase, promoted, rn = step(phase, promoted, rn)
+    phase, promoted, rn = reset()
+    hist, phases = [], []
+    for sv in solvers.values():
+        sv.exchanges = 0
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
-        solver.cycle(0)
-        hist.append(solver.residual_norm())
+        phase, promoted, rn = step(phase, promoted, rn)
+        hist.append(rn)
+        phases.append(phase)
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    # roofline leg (rank 0): the local level-0 Jacobi sweep, timed with events on the stream it is launched on
-    d0 = solver.doms[rank]
-    b0 = d0.blk[0]
-    hx0, hy0 = solver.h[0]
+    # roofline leg (rank 0): the dominant kernel of the timed region -- the level-0 up leg (prolongation + 2 sweeps +
+    # norm) of the precision that ran most cycles -- on this rank's block, timed with events on its own stream
+    dom = "f64" if phases.count("f64") >= phases.count("f32") else "f32"
+    sv = solvers[dom]
+    d0 = sv.doms[rank]
+    b0, b1 = d0.blk[0], d0.blk[1]
+    hx0, hy0 = sv.h[0]
+    ci, cj = b0.coarse_offsets(b1)
+    e = d0.ec if sv.Ld == 1 else d0.u[1]
+    win = (max(b0.i_lo, 1), min(b0.i_hi, b0.lnx - 1), max(b0.j_lo, 1), min(b0.j_hi, b0.lny - 1))
+
+    def leg():
+        sv.ops.up_leg(sv.smk, d0.u[0], d0.rhs[0], d0.t[0], e, b0.lnx, b0.lny, b1.lnx, b1.lny, ci, cj, b0.sides, hx0, hy0,
+                      sv.omega, sv.coeff, sv.post, (b0.gx0 + b0.gy0) & 1, win)
     reps = 20
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ops.jacobi(d0.u[0], d0.rhs[0], d0.t[0], b0.lnx, b0.lny, hx0, hy0, 0.8)
+    leg()
     ev0.record()
     for _ in range(reps):
-        ops.jacobi(d0.u[0], d0.rhs[0], d0.t[0], b0.lnx, b0.lny, hx0, hy0, 0.8)
+        leg()
     ev1.record()
     torch.cuda.synchronize()
-    ms_j = ev0.elapsed_time(ev1) / reps
-    alg = 3 * 4 * b0.lnx * b0.lny
+    ms_leg = ev0.elapsed_time(ev1) / reps
+    w = 8 if dom == "f64" else 4
+    alg, comp = 10.25 * w * b0.lnx * b0.lny, 3.25 * w * b0.lnx * b0.lny
     if rank == 0:
         value = NX * NY * K / dt / 1e6
+        s0 = solvers["f64"]
         print(json.dumps({
             "metric": "MDoF/s per V-cycle", "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"2D Poisson {NX}x{NY} fp32 (coarsest level fp64), V(2,2) weighted-Jacobi omega=0.8, {px}x{py} block "
-                                   f"decomposition ({args.n}^2 per GPU), RCCL halo exchange ({solver.mode} legs, ghost width "
-                                   f"{solver.G}), {solver.L} levels ({solver.Ld} distributed, rest replicated after all-gather)",
-                       "grid": [NX, NY], "levels": solver.L, "cycle": "V(2,2)", "smoother": "jacobi",
+            "dtype": "f32->f64 (adaptive)", "data": "synthetic",
+            "config": {"workload": f"2D Poisson {NX}x{NY} adaptive fp32->fp64 (switch_threshold={thr:g}), V(2,2) weighted-Jacobi "
+                                   f"omega=0.8, {px}x{py} block decomposition ({args.n}^2 per GPU), RCCL halo exchange ({s0.mode} legs, "
+                                   f"ghost width {s0.G}), {s0.L} levels ({s0.Ld} distributed, rest replicated after all-gather)",
+                       "grid": [NX, NY], "levels": s0.L, "cycle": "V(2,2)", "smoother": "jacobi",
                        "parallelism": f"dd{px}x{py}"},
+            "cycles_fp32": phases.count("f32"), "cycles_fp64": phases.count("f64"),
             "residual_first": hist[0], "residual_last": hist[-1],
-            "roofline": {"bound": "hbm", "kernel": f"jacobi_kernel<float,0> local {b0.lnx}x{b0.lny} fp32 sweep (rank 0)",
-                         "achieved": alg / (ms_j * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg / (ms_j * 1e-3) / 1e9 / 8000.0, "traffic": None, "launch_ms": ms_j,
-                         "algorithmic_bytes_per_launch": alg},
-            "exchanges_per_cycle": solver.exchanges / max(1, K + W + 0),
+            "roofline": {"bound": "hbm", "kernel": f"fused_jacobi_kernel up_leg {dom} on the local {b0.lnx}x{b0.lny} block (rank 0, level 0)",
+                         "achieved": alg / (ms_leg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": alg / (ms_leg * 1e-3) / 1e9 / 8000.0, "traffic": None, "launch_ms": ms_leg,
+                         "algorithmic_bytes_per_launch": alg, "compulsory_bytes_per_launch": comp,
+                         "compulsory_gbs": comp / (ms_leg * 1e-3) / 1e9, "compulsory_frac": comp / (ms_leg * 1e-3) / 1e9 / 8000.0,
+                         "note": "achieved = algorithmic bytes (SURVEY 8d per-operator accounting) / launch time; a fused leg "
+                                 "moves the fields once (compulsory_*)"},
+            "exchanges_per_cycle": sum(x.exchanges for x in solvers.values()) / max(1, K),
             "note": "distributed levels: communication-avoiding fused legs (two launches and about one halo exchange per "
                     "level and cycle, orchestrated from Python over torch.distributed P2P); the replicated coarse "
-                    "hierarchy runs on the fused single-GPU engine",
+                    "hierarchy runs on the fused single-GPU engine; same precision policy as the N = 1 line",
         }))
-    solver.close()
+    for x in solvers.values():
+        x.close()
     dist.destroy_process_group()

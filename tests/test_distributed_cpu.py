@@ -172,3 +172,40 @@ def test_gloo_multiprocess_fused_mode(tmp_path, world, cyc):
     u_ref, h_ref = _oracle(129, 129, 5, cyc, "jacobi", 0.8, 3)
     np.testing.assert_array_equal(res["u"], u_ref)
     np.testing.assert_allclose(res["hist"], h_ref, rtol=1e-13)
+
+
+def test_precision_switch_between_two_decomposed_solvers():
+    """bench.py --gpus N runs the adaptive policy on two solvers that share the decomposition (fp32 and fp64):
+    take_iterate_from must hand over the whole local iterate, ghost zone included, so that the continued cycles
+    equal the single-domain oracle that casts its iterate at the same point."""
+    NX = NY = 129
+    dom = (0.0, 1.0, 0.0, 1.0)
+    levels = len(D.hierarchy_shapes(NX, NY, 99))
+    rhs64 = O.sine_rhs(NX, NY, dom)
+    # single domain: 2 cycles in fp32, cast, 2 cycles in fp64
+    o32 = O.MGOracle(NX, NY, dom, np.float32, -1.0, levels, "V", 2, 2, "jacobi", 0.8, "vectorized")
+    o64 = O.MGOracle(NX, NY, dom, np.float64, -1.0, levels, "V", 2, 2, "jacobi", 0.8, "vectorized")
+    o32.rhs[0] = rhs64.astype(np.float32); o64.rhs[0] = rhs64.copy()
+    u = np.zeros((NX, NY), dtype=np.float32)
+    for _ in range(2):
+        u = o32.cycle_once(u, 0)
+    u = u.astype(np.float64)
+    h_ref = []
+    for _ in range(2):
+        u = o64.cycle_once(u, 0)
+        h_ref.append(o64.residual_norm(u, rhs64, 0))
+    # decomposed, 2 x 2 virtual ranks, fused mode
+    sol = {}
+    for name, dt in (("f32", np.float32), ("f64", np.float64)):
+        sol[name] = D.DistributedMultigrid(NX, NY, 2, 2, range(4), H.NumpyOps(dt), None, domain=dom, max_levels=levels, cycle="V",
+                                           smoother="jacobi", omega=0.8, agglomerate_at=33, mode="fused")
+        sol[name].set_problem(lambda b: rhs64[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+    for _ in range(2):
+        sol["f32"].cycle(0)
+    sol["f64"].take_iterate_from(sol["f32"])
+    hist = []
+    for _ in range(2):
+        sol["f64"].cycle(0)
+        hist.append(sol["f64"].residual_norm())
+    np.testing.assert_array_equal(H.assemble(sol["f64"], NX, NY), u)
+    np.testing.assert_allclose(hist, h_ref, rtol=1e-12)
