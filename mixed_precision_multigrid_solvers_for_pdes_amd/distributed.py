@@ -646,6 +646,46 @@ def sine_rhs_block(b, domain=(0.0, 1.0, 0.0, 1.0)):
 # ------------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): weak scaling, 4097^2 points per GPU
 # ------------------------------------------------------------------------------------------------
+def stagnating(hist):
+    """should_promote_precision on the last five residual norms (core/precision.py:189-246; csrc/mghip.hip: stagnating)."""
+    if len(hist) < 5:
+        return False
+    r = hist[-5:]
+    ratios = [r[i] / r[i - 1] for i in range(1, 5) if r[i - 1] > 0]
+    if ratios:
+        if sum(ratios) / len(ratios) > 0.9:
+            return True
+        rel = [abs(r[i] - r[i - 1]) / r[i - 1] for i in range(1, 5) if r[i - 1] > 0]
+        if rel and sum(rel) / len(rel) < 1e-3:
+            return True
+    return all(r[i] >= r[i - 1] * 0.99 for i in range(1, 5))
+
+
+class AdaptivePolicy:
+    """The engine's adaptive rule (csrc/mghip.hip: adapt, one-way variant of core/precision.py:270-302) as host logic
+    for drivers that hold one solver per precision: start in double, drop to single on a large first residual,
+    promote for good when ||r|| < 10 thr or the fp32 iteration stagnates."""
+
+    def __init__(self, thr):
+        self.thr, self.phase, self.promoted, self.hist = thr, "f64", False, []
+
+    def before_cycle(self, rn):
+        """-> the precision the coming cycle runs in (the caller moves the iterate when it differs from .phase)"""
+        want = self.phase
+        if not self.promoted:
+            if self.phase == "f64" and rn > 100.0 * self.thr and not self.hist:
+                want = "f32"
+            elif self.phase == "f32" and (rn < 10.0 * self.thr or stagnating(self.hist)):
+                want, self.promoted = "f64", True
+        if want != self.phase:
+            self.phase = want
+            self.hist = []
+        return want
+
+    def after_cycle(self, rn):
+        self.hist.append(rn)
+
+
 def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1): BASELINE config 3's workload per GPU (4097^2, adaptive fp32 -> fp64, V(2,2) weighted
     Jacobi) on a px x py block decomposition -- weak scaling of the N = 1 bench line.  The precision policy is the
@@ -678,26 +718,24 @@ def bench_main(args, rank, local_rank, world):
     def reset():
         for sv in solvers.values():
             sv.set_problem(lambda b: sine_rhs_block(b, domain))
-        return "f64", False, solvers["f64"].residual_norm()
+        return AdaptivePolicy(thr), solvers["f64"].residual_norm()
 
-    def step(phase, promoted, rn):
+    def step(policy, rn):
         """policy check (before the cycle, solvers/multigrid.py:224-227) -> cycle -> norm"""
-        want = phase
-        if phase == "f64" and not promoted and rn > 100.0 * thr:
-            want = "f32"
-        elif phase == "f32" and rn < 10.0 * thr:
-            want, promoted = "f64", True
-        if want != phase:
-            solvers[want].take_iterate_from(solvers[phase])
-            phase = want
-        solvers[phase].cycle(0)
-        return phase, promoted, solvers[phase].residual_norm()
+        had = policy.phase
+        now = policy.before_cycle(rn)
+        if now != had:
+            solvers[now].take_iterate_from(solvers[had])
+        solvers[now].cycle(0)
+        rn = solvers[now].residual_norm()
+        policy.after_cycle(rn)
+        return rn
 
     K, W = args.steps, args.warmup
-    phase, promoted, rn = reset()
+    policy, rn = reset()
     for _ in range(W):
-        phase, promoted, rn = step(phase, promoted, rn)
-    phase, promoted, rn = reset()
+        rn = step(policy, rn)
+    policy, rn = reset()
     hist, phases = [], []
     for sv in solvers.values():
         sv.exchanges = 0
@@ -705,9 +743,9 @@ def bench_main(args, rank, local_rank, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
-        phase, promoted, rn = step(phase, promoted, rn)
+        rn = step(policy, rn)
         hist.append(rn)
-        phases.append(phase)
+        phases.append(policy.phase)
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0

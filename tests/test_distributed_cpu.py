@@ -209,3 +209,26 @@ def test_precision_switch_between_two_decomposed_solvers():
         hist.append(sol["f64"].residual_norm())
     np.testing.assert_array_equal(H.assemble(sol["f64"], NX, NY), u)
     np.testing.assert_allclose(hist, h_ref, rtol=1e-12)
+
+
+def test_adaptive_policy_host_port():
+    """distributed.AdaptivePolicy = csrc/mghip.hip adapt() (one-way rule): the trajectory of the 4097^2 bench problem
+    (fp32 stagnates at its residual floor, the stagnation rule promotes after five cycles) and the threshold path."""
+    p = D.AdaptivePolicy(1e-6)
+    assert p.before_cycle(9.87) == "f32"                       # large first residual: single
+    floor = [2.15, 2.05, 2.04, 2.045, 2.05]
+    for rn in floor:
+        p.after_cycle(rn)
+        if rn is not floor[-1]:
+            assert p.before_cycle(rn) == "f32"
+    assert p.before_cycle(floor[-1]) == "f64" and p.promoted    # mean ratio of the last five > 0.9
+    for rn in (0.2, 9.9, 1e-9):
+        p.after_cycle(rn)
+        assert p.before_cycle(rn) == "f64"                      # promoted for good
+    q = D.AdaptivePolicy(1e-3)
+    assert q.before_cycle(5.0) == "f32"
+    q.after_cycle(5e-3)
+    assert q.before_cycle(5e-3) == "f64"                        # below 10 thr
+    r = D.AdaptivePolicy(1e-6)
+    assert r.before_cycle(5e-5) == "f64"                        # small first residual: stay in double
+    assert not D.stagnating([1.0, 0.1, 0.01, 0.001, 0.0001]) and D.stagnating([1.0, 1.0, 1.0, 1.0, 1.0])
