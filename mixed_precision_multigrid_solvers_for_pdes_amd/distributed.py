@@ -316,6 +316,7 @@ class DistributedMultigrid:
             self.gmx = max(b.i_hi - b.i_lo for b in blocks)
             self.gmy = max(b.j_hi - b.j_lo for b in blocks)
         self._last_norm_parts = None
+        self._stage_p2p = None                   # decided at the first exchange (see _p2p)
         # exchange / compute overlap on a second stream (device kernels only)
         self.overlap = bool(overlap) and self.mode == "fused" and getattr(ops, "supports_overlap", False)
         if self.overlap:
@@ -333,6 +334,22 @@ class DistributedMultigrid:
     def _p2p(self, sends, recvs):
         """sends/recvs: lists of (peer_rank, tensor): batched isend/irecv (RCCL send/recv, one group per phase)."""
         if self.dist is None or not (sends or recvs):
+            return
+        if self._stage_p2p is None:
+            # gloo moves device tensors with host-side memcpy on their raw pointers, unordered against the HIP streams
+            # that produce / consume them (rehearsals on a one-GPU box): stage through host tensors, synchronously.
+            # nccl (= RCCL) send/recv are enqueued on the current stream and need nothing of the kind.
+            self._stage_p2p = (self.dist.get_backend() == "gloo") and any(t.is_cuda for _, t in sends + recvs)
+        if self._stage_p2p:
+            self.torch.cuda.current_stream().synchronize()
+            hs = [(p, t.cpu()) for p, t in sends]
+            hr = [(p, self.torch.empty(t.shape, dtype=t.dtype), t) for p, t in recvs]
+            ops = [self.dist.P2POp(self.dist.isend, t, p) for p, t in hs] + \
+                  [self.dist.P2POp(self.dist.irecv, h, p) for p, h, _ in hr]
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+            for _, h, t in hr:
+                t.copy_(h)
             return
         ops = [self.dist.P2POp(self.dist.isend, t, p) for p, t in sends] + \
               [self.dist.P2POp(self.dist.irecv, t, p) for p, t in recvs]
