@@ -104,15 +104,16 @@ class Block:
 
 def distributed_levels(shapes, px, py, agglomerate_at, G=1):
     """Number of leading levels that stay distributed.  A level is distributed while its cuts are even
-    (so the next level lines up), its blocks own at least max(4, G + 1) rows/cols and it is larger than
-    `agglomerate_at` points in some direction; at least one level is always left for the replicated part."""
+    (so the next level lines up), its blocks own at least max(4, G + 1) rows/cols -- and those of the level below
+    at least G, whose ghost zone the correction is cut out for -- and it is larger than `agglomerate_at` points in
+    some direction; at least one level is always left for the replicated part."""
     n = 0
     need = max(4, G + 1)
     for (NX, NY) in shapes[:-1]:
         if (NX - 1) % px or (NY - 1) % py:
             break
         mx, my = (NX - 1) // px, (NY - 1) // py
-        if (px > 1 and (mx % 2 or mx < need)) or (py > 1 and (my % 2 or my < need)):
+        if (px > 1 and (mx % 2 or mx < need or mx // 2 < G)) or (py > 1 and (my % 2 or my < need or my // 2 < G)):
             break
         if max(NX, NY) <= agglomerate_at:
             break
@@ -244,7 +245,11 @@ class _Dom:
     """Per-rank state: one Block per distributed level and its fields."""
 
 
-GHOST_FUSED = 7      # smallest odd ghost width for which owned cells stay exact through a fused V(2,2) visit (Jacobi)
+# Ghost width of the fused mode: the smallest odd G for which the owned cells stay exact through every fused visit.
+# With s = halo cells a leg's two sweeps consume (Jacobi 2, red-black GS 4: one per colour pass), m exact ghost cells
+# after the up leg of a level and m_c on the level below: m = min(G - s, 2 m_c - 1) - s; the recursion must reproduce
+# itself (m_c = m) and leave m >= 1 for the norm: Jacobi m = 3, G = 7; red-black GS m = 5, G = 13.
+GHOST_FUSED = {"jacobi": 7, "rbgs": 13}
 
 
 class DistributedMultigrid:
@@ -254,9 +259,9 @@ class DistributedMultigrid:
             in-process virtual-rank mode used by the single-GPU test).
     ops:    kernel provider (HipOps, or the tests' NumPy stand-in).
     dist:   torch.distributed module (initialised) or None for the in-process mode.
-    mode:   "fused" (ghost zone of 7 cells, two fused launches and ~one exchange per level; weighted Jacobi with
-            pre, post <= 2) or "per_operator" (1-cell ghost ring, one launch and one exchange per operator; any
-            smoother / sweep count).  "auto" picks "fused" whenever it applies.
+    mode:   "fused" (ghost zone of 7 cells for weighted Jacobi, 13 for red-black GS; two fused launches and ~one
+            exchange per level; pre, post <= 2) or "per_operator" (1-cell ghost ring, one launch and one exchange per
+            operator; any sweep count).  "auto" picks "fused" whenever it applies.
     """
 
     def __init__(self, NX, NY, px, py, ranks, ops, dist=None, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0,
@@ -272,11 +277,11 @@ class DistributedMultigrid:
             raise ValueError(f"Unknown smoother: {smoother}")
         if mode not in ("auto", "fused", "per_operator"):
             raise ValueError(f"Unknown mode: {mode}")
-        can_fuse = smoother == "jacobi" and pre <= 2 and post <= 2 and hasattr(ops, "down_leg")
+        can_fuse = pre <= 2 and post <= 2 and hasattr(ops, "down_leg")
         if mode == "fused" and not can_fuse:
-            raise ValueError("mode 'fused' needs weighted Jacobi with pre, post <= 2")
+            raise ValueError("mode 'fused' needs pre, post <= 2")
         self.mode = "fused" if (mode in ("auto", "fused") and can_fuse) else "per_operator"
-        self.G = GHOST_FUSED if self.mode == "fused" else 1
+        self.G = GHOST_FUSED[smoother] if self.mode == "fused" else 1
         self.smoother, self.omega = smoother, omega
         self.smk = _lib.MG_JACOBI if smoother == "jacobi" else _lib.MG_RBGS
         self.shapes = hierarchy_shapes(NX, NY, max_levels or default_max_levels(NX, NY))

@@ -95,12 +95,29 @@ class NumpyOps:
             P = np.where((io == 0) & (jo == 1) & (i == lnxf - 1), 0.0, P)
         return P.astype(dtype), valid
 
+    def _sweeps(self, sm, v, f, hx, hy, omega, nsweep, poff):
+        """nsweep sweeps of the local array: weighted Jacobi (sm = 0) or red-black GS with the global colouring (sm = 1)."""
+        if sm == 0:
+            return O.jacobi(v, f, hx, hy, omega, nsweep, "vectorized")
+        v = v.copy()
+        lnx, lny = v.shape
+        diag = -2.0 / hx**2 - 2.0 / hy**2
+        i = np.arange(1, lnx - 1)[:, None]; j = np.arange(1, lny - 1)[None, :]
+        for _ in range(nsweep):
+            for colour in (0, 1):
+                m = ((i + j + poff) % 2) == colour
+                nb = (v[2:, 1:-1] + v[:-2, 1:-1]) / hx**2 + (v[1:-1, 2:] + v[1:-1, :-2]) / hy**2
+                upd = (1 - omega) * v[1:-1, 1:-1] + omega * ((f[1:-1, 1:-1] + nb) / (-diag))
+                inner = v[1:-1, 1:-1]
+                inner[m] = upd[m]
+        return v
+
     def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff,
                  select=0, inner=None):
         assert select == 0          # no streams on the CPU: the driver never splits the launch here
         f = self._v(rhs, lnx, lny)
         v = np.zeros_like(f) if zero_init else self._v(u, lnx, lny).copy()
-        v = O.jacobi(v, f, hx, hy, omega, nsweep, "vectorized")
+        v = self._sweeps(sm, v, f, hx, hy, omega, nsweep, poff)
         self._v(out, lnx, lny)[1:, :] = v[1:, :]                    # the kernel never writes row 0
         r = O.residual(v, f, hx, hy, coeff)
         c = self._v(rhs_c, lnxc, lnyc)
@@ -117,7 +134,7 @@ class NumpyOps:
         v = self._v(u, lnx, lny).copy()
         P, valid = self._prolong_field(self._v(e_c, lnxc, lnyc), lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, v.dtype)
         v[valid] = (v + P)[valid]
-        v = O.jacobi(v, f, hx, hy, omega, nsweep, "vectorized")
+        v = self._sweeps(sm, v, f, hx, hy, omega, nsweep, poff)
         self._v(out, lnx, lny)[1:, :] = v[1:, :]
         if window is None:
             return None

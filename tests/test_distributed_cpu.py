@@ -103,6 +103,18 @@ def test_fused_mode_virtual_ranks_equal_single_domain(px, py, NX, NY, agg, cyc, 
         assert s.exchanges == 3 * (1 + (s.Ld - 1))          # per cycle: the fine iterate + one per distributed coarse rhs
 
 
+@pytest.mark.parametrize("px,py,NX,NY,agg", [(2, 1, 257, 129, 65), (2, 2, 257, 257, 65), (1, 2, 129, 257, 33)])
+@pytest.mark.parametrize("cyc,omega", [("V", 1.0), ("W", 1.15)])
+def test_fused_mode_red_black_virtual_ranks_equal_single_domain(px, py, NX, NY, agg, cyc, omega):
+    """Red-black GS in the communication-avoiding mode: a colour pass costs one ghost cell, G = 13."""
+    levels = len(D.hierarchy_shapes(NX, NY, 99))
+    u_ref, h_ref = _oracle(NX, NY, levels, cyc, "rbgs", omega, 3)
+    s, hist = _run_ranks(NX, NY, px, py, range(px * py), None, levels, cyc, "rbgs", omega, 3, agg=agg, mode="fused")
+    assert s.mode == "fused" and s.G == 13 and s.Ld >= 1
+    np.testing.assert_array_equal(H.assemble(s, NX, NY), u_ref)
+    np.testing.assert_allclose(hist, h_ref, rtol=1e-13)
+
+
 def test_fused_mode_block_bookkeeping():
     b0, b1 = D.Block(8193, 4097, 2, 1, 0, 0, 7), D.Block(8193, 4097, 2, 1, 1, 0, 7)
     assert (b0.gx0, b0.lnx, b0.oi_lo, b0.oi_hi) == (0, 4097 + 7, 1, 4096)          # rows 0 .. 4096+7
