@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32, "managed32"])
 @pytest.mark.parametrize("px,py,NX,NY,agg", [(2, 1, 513, 257, 65), (2, 2, 513, 513, 129), (4, 2, 1025, 513, 129), (1, 2, 257, 1025, 33)])
 @pytest.mark.parametrize("cyc,kind,omega,mode", [("V", "jacobi", 0.8, "per_operator"), ("W", "rbgs", 1.0, "per_operator"),
-                                                 ("V", "jacobi", 0.8, "fused"), ("W", "jacobi", 0.8, "fused")])
+                                                 ("V", "jacobi", 0.8, "fused"), ("W", "jacobi", 0.8, "fused"),
+                                                 ("V", "rbgs", 1.0, "fused"), ("W", "rbgs", 1.15, "fused")])
 def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cyc, kind, omega, mode):
     import torch
     managed = dtype == "managed32"
@@ -61,6 +62,7 @@ def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cy
     # BASELINE config 5's decomposition and cycle: 16385^2, W(2,2) red-black GS, 2 x 4 blocks of 8193 x 4097
     # (fp64 here: the distributed driver runs one precision on its distributed levels)
     ("config5", 2, 4, 16385, 16385, np.float64, "W", "rbgs", 1.0, "per_operator"),
+    ("config5", 2, 4, 16385, 16385, np.float64, "W", "rbgs", 1.0, "fused"),
 ])
 def test_full_size_configs_as_virtual_ranks(name, px, py, NX, NY, dtype, cyc, kind, omega, mode):
     """The multi-GPU configurations of BASELINE.json at their full sizes, all ranks as virtual ranks on ONE GPU
