@@ -12,12 +12,13 @@ decomposition-invariant by construction:
     that is either the physical boundary or a ghost copy of the neighbour's edge.  Local cell (0,0) has
     an even global index, so coarse cell (ic, jc) sits on local fine cell (2ic, 2jc) on every rank and
     the red/black colouring is the global one;
-  * mode "fused" (default; communication-avoiding): every rank keeps a ghost ZONE of G = 7 cells and runs the same
+  * mode "fused" (default; communication-avoiding): every rank keeps a ghost ZONE of G cells and runs the same
     two fused kernels per level as the single-GPU engine (down leg: 2 sweeps + residual + restriction; up leg:
     prolongation + 2 sweeps [+ norm]) on its whole local array, recomputing inside the ghost zone what the
-    neighbour computes too; each sweep / residual / transfer invalidates one more ghost cell from the outside,
-    and G = 7 is the smallest odd width for which the owned cells stay exact through a whole V(2,2) visit.
-    Exchanges per cycle: the fine iterate once (7 rows / columns per neighbour) and each coarse right-hand side
+    neighbour computes too; each Jacobi sweep / GS colour pass / residual / transfer invalidates one more ghost
+    cell from the outside; G = 7 (weighted Jacobi) and G = 13 (red-black GS) are the smallest odd widths for
+    which the owned cells stay exact through every V / W / F visit (GHOST_FUSED below).
+    Exchanges per cycle: the fine iterate once (G rows / columns per neighbour) and each coarse right-hand side
     once -- L_d + 1 exchanges instead of 5 L_d, each a few hundred KB instead of 16 KB, and two launches per level;
   * mode "per_operator": 1-cell ghost ring, one launch per operator (the kernels pass the ring through); every
     sweep (every colour) is followed by a halo exchange of u; the residual gets one exchange (with corners)
@@ -28,8 +29,8 @@ decomposition-invariant by construction:
     back, no latency-bound tiny halo messages;
   * ||r|| is an all-reduce of one fp64 partial sum per rank over exactly the cells each rank owns.
 
-Messages are 1 row / 1 column (16-32 KB at 4097^2 per GPU): latency-bound, each neighbour pair on its
-own xGMI link.  Fields live in torch tensors (device memory, streams); the arithmetic is libmghip's
+Messages are G rows / columns (118 KB at 4097^2 fp32, G = 7; 16-32 KB per 1-cell ring in per-operator mode):
+latency-bound, each neighbour pair on its own xGMI link.  Fields live in torch tensors (device memory, streams); the arithmetic is libmghip's
 device-pointer entry points (mg_dev_*).  `ops` and `comm` are injected so that the decomposition logic
 runs unchanged (a) on CPU under gloo with a NumPy stand-in for the kernels (tests) and (b) with several
 virtual ranks in one process on one GPU (tests), besides (c) the real thing.
