@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Cycle times of the BASELINE configurations that fit one GPU (device-resident, mg_iterate, tol = 0).
+
+    python3 tools/config_times.py
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mixed_precision_multigrid_solvers_for_pdes_amd as mg          # noqa: E402
+from mixed_precision_multigrid_solvers_for_pdes_amd import _lib      # noqa: E402
+
+CASES = [("config 1 size: 129^2 fp64 V(2,2) Jacobi", 129, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_DOUBLE, 20),
+         ("config 2: 1025^2 fp64 V(2,2) Jacobi", 1025, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_DOUBLE, 20),
+         ("config 3: 4097^2 adaptive V(2,2) Jacobi", 4097, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_ADAPTIVE, 20),
+         ("4097^2 fp64 V(2,2) red-black GS", 4097, "V", _lib.MG_RBGS, 1.0, _lib.MG_PREC_DOUBLE, 10),
+         ("4097^2 fp64 W(2,2) red-black GS", 4097, "W", _lib.MG_RBGS, 1.0, _lib.MG_PREC_DOUBLE, 5),
+         ("config 4 size on one GPU: 8193^2 fp32 (fp64 coarsest) V(2,2) Jacobi", 8193, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_SINGLE_MANAGED, 10),
+         ("8193^2 adaptive V(2,2) Jacobi", 8193, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_ADAPTIVE, 20),
+         ("config 5 on one GPU: 16385^2 mixed W(2,2) red-black GS", 16385, "W", _lib.MG_RBGS, 1.0, _lib.MG_PREC_MIXED_LEVELS, 3),
+         ("16385^2 mixed V(2,2) Jacobi", 16385, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_MIXED_LEVELS, 5)]
+for name, n, cyc, sm, omega, prec, its in CASES:
+    x = np.linspace(0, 1, n)
+    rhs = 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
+    eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), cycle=cyc, smoother=sm, omega=omega, precision=prec)
+    eng.set_rhs(rhs)
+    eng.set_solution(None)
+    eng.iterate(0.0, 2)                                   # warm-up
+    eng.set_solution(None)
+    r = eng.iterate(0.0, its)
+    ms = r["solve_seconds"] / r["iterations"] * 1e3
+    print(f"{name:72s} {ms:9.3f} ms/cycle  {n * n / ms / 1e6:8.2f} GDoF/s  ||r|| {r['residual_history'][0]:.2e} -> {r['residual_history'][-1]:.2e}", flush=True)
+    eng.close()
