@@ -85,7 +85,7 @@ def _on_arrays(fn, *args):
             return out
         if out.shape == ():
             return np.full(shape, float(out))
-    except Exception:
+    except (TypeError, ValueError):        # written for scalars (math.sin(x), `if x < 0.5`, ...): evaluate point by point
         pass
     return np.asarray(np.vectorize(fn, otypes=[np.float64])(*args), dtype=np.float64).reshape(shape)
 
