@@ -1,6 +1,8 @@
-"""Seeded random shapes / domains / cycles against the oracle: odd hierarchies (coarsest grids that are not 5 x 5,
+"""Seeded random shapes / domains / cycles against the oracle (MG_FUZZ_OPS / MG_FUZZ_CYCLES / MG_FUZZ_SEED widen the sweep): odd hierarchies (coarsest grids that are not 5 x 5,
 non-square, a coarsening that stops early because (n - 1) turns odd), both precisions, all smoothers, fused and
 one-launch-per-operator cycles.  Bit equality where the spacing is dyadic, a few ulp otherwise."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,7 +27,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("k,nx,ny,domain,dyadic", _cases(24, 2024))
+@pytest.mark.parametrize("k,nx,ny,domain,dyadic", _cases(int(os.environ.get("MG_FUZZ_OPS", 24)), int(os.environ.get("MG_FUZZ_SEED", 2024))))
 def test_random_shapes_operators(k, nx, ny, domain, dyadic):
     rng = np.random.default_rng(1000 + k)
     dt = np.float64 if k % 3 else np.float32
@@ -50,7 +52,7 @@ def test_random_shapes_operators(k, nx, ny, domain, dyadic):
         same(mg.ProlongationOperator("bilinear").apply(coarse, e, grid), O.prolong_bilinear(e))
 
 
-@pytest.mark.parametrize("k,nx,ny,domain,dyadic", _cases(16, 7))
+@pytest.mark.parametrize("k,nx,ny,domain,dyadic", _cases(int(os.environ.get("MG_FUZZ_CYCLES", 16)), int(os.environ.get("MG_FUZZ_SEED", 2024)) + 7))
 def test_random_shapes_cycles(k, nx, ny, domain, dyadic):
     rng = np.random.default_rng(2000 + k)
     cyc = ["V", "W", "V", "F"][k % 4]
