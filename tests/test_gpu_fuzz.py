@@ -76,3 +76,56 @@ def test_random_shapes_cycles(k, nx, ny, domain, dyadic):
         # (a tiny grid is solved to rounding level by the coarsest solver alone: compare such norms absolutely)
         np.testing.assert_allclose(r["residual_history"], info["residual_history"], rtol=1e-8, atol=1e-11 * np.max(np.abs(rhs)))
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def _dd_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        px, py = [(2, 1), (1, 2), (2, 2), (4, 2), (2, 4), (4, 1)][int(rng.integers(0, 6))]
+        fx, fy = rng.choice([1, 3, 5], 2)
+        ax, ay = rng.integers(5, 8, 2)
+        NX, NY = int(px * fx * 2**ax + 1), int(py * fy * 2**ay + 1)
+        kind, omega = [("jacobi", 0.8), ("rbgs", 1.0)][int(rng.integers(0, 2))]
+        cyc = ["V", "W"][int(rng.integers(0, 2))]
+        mode = ["fused", "per_operator"][int(rng.integers(0, 3) == 0)]
+        agg = int(rng.choice([33, 65, 129]))
+        out.append((k, px, py, NX, NY, kind, omega, cyc, mode, agg))
+    return out
+
+
+@pytest.mark.parametrize("k,px,py,NX,NY,kind,omega,cyc,mode,agg",
+                         _dd_cases(int(os.environ.get("MG_FUZZ_DD", 10)), int(os.environ.get("MG_FUZZ_SEED", 2024)) + 13))
+def test_random_decompositions_equal_single_engine(k, px, py, NX, NY, kind, omega, cyc, mode, agg):
+    """Random process grids / block sizes (odd factors: blocks whose coarse levels stop lining up early) / smoothers /
+    cycles / modes as virtual ranks on one GPU: bit-identical to the single-domain engine."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    import dist_helpers as H
+    from mixed_precision_multigrid_solvers_for_pdes_amd import distributed as D
+    rng = np.random.default_rng(3000 + k)
+    rhs = rng.standard_normal((NX, NY)); u0 = rng.standard_normal((NX, NY))
+    levels = mg.default_max_levels(NX, NY)
+    ops = D.HipOps(np.float64, torch.device("cuda", 0))
+    s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle=cyc, smoother=kind, omega=omega,
+                               agglomerate_at=agg, mode=mode, coarse_maxit=50)
+    if s.Ld == 0:
+        s.close()
+        pytest.skip("nothing stays distributed for this shape")
+    eng = mg.MultigridEngine(NX, NY, max_levels=levels, cycle=cyc, smoother=_lib.MG_JACOBI if kind == "jacobi" else _lib.MG_RBGS,
+                             omega=omega, coarse_maxit=50)
+    eng.set_rhs(rhs); eng.set_solution(u0)
+    ref_hist = []
+    for _ in range(2):
+        eng.cycle(1); ref_hist.append(eng.residual_norm())
+    u_ref = eng.get_solution(np.float64)
+    eng.close()
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+    hist = []
+    for _ in range(2):
+        s.cycle(0); hist.append(s.residual_norm())
+    u = H.assemble(s, NX, NY, np.float64)
+    s.close()
+    np.testing.assert_array_equal(u, u_ref)
+    np.testing.assert_allclose(hist, ref_hist, rtol=1e-12)
