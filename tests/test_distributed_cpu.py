@@ -162,7 +162,8 @@ def _worker(rank, world, port, px, py, cyc, kind, omega, out_path, mode="per_ope
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cyc,kind,omega", [(2, "V", "jacobi", 0.8), (2, "W", "rbgs", 1.0), (4, "V", "rbgs", 1.0), (4, "W", "jacobi", 0.8)])
+@pytest.mark.parametrize("world,cyc,kind,omega", [(2, "V", "jacobi", 0.8), (2, "W", "rbgs", 1.0), (4, "V", "rbgs", 1.0), (4, "W", "jacobi", 0.8),
+                                                  (8, "V", "jacobi", 0.8)])
 def test_gloo_multiprocess_equals_single_domain(tmp_path, world, cyc, kind, omega):
     import torch.multiprocessing as mp
     px, py = D.process_grid(world)
@@ -174,7 +175,7 @@ def test_gloo_multiprocess_equals_single_domain(tmp_path, world, cyc, kind, omeg
     np.testing.assert_allclose(res["hist"], h_ref, rtol=1e-13)
 
 
-@pytest.mark.parametrize("world,cyc", [(2, "V"), (4, "V"), (4, "W")])
+@pytest.mark.parametrize("world,cyc", [(2, "V"), (4, "V"), (4, "W"), (8, "V")])       # 8: the 4 x 2 grid of the 8-GPU node
 def test_gloo_multiprocess_fused_mode(tmp_path, world, cyc):
     import torch.multiprocessing as mp
     px, py = D.process_grid(world)
