@@ -954,9 +954,11 @@ bool stagnating(const std::vector<double>& hist) {
   return inc;
 }
 
-// core/precision.py:270-302 update_precision (+ the one-way variant documented in mghip.h)
-int adapt(mg_handle* h, double rn) {
-  if (h->cfg.precision != MG_PREC_ADAPTIVE) return MG_OK;
+// core/precision.py:270-302 update_precision (+ the one-way variant documented in mghip.h): the precision the coming
+// cycle runs in.  Pure -- `*promote` says whether taking the decision also ends the adaptive phase for good.
+int adapt_target(const mg_handle* h, double rn, bool* promote) {
+  *promote = false;
+  if (h->cfg.precision != MG_PREC_ADAPTIVE) return h->phase;
   const double thr = h->cfg.switch_threshold;
   double pts = 0;
   for (auto& l : h->lv) pts += (double)l.nx * l.ny;
@@ -968,8 +970,15 @@ int adapt(mg_handle* h, double rn) {
     else if (h->phase == MG_F32 && rn < thr * 10) to = MG_F64;
   } else if (!h->promoted) {
     if (h->phase == MG_F64 && (mem_down || rn > thr * 100) && h->adapt_hist.empty()) to = MG_F32;
-    else if (h->phase == MG_F32 && (rn < thr * 10 || stagnating(h->adapt_hist))) { to = MG_F64; h->promoted = true; }
+    else if (h->phase == MG_F32 && (rn < thr * 10 || stagnating(h->adapt_hist))) { to = MG_F64; *promote = true; }
   }
+  return to;
+}
+
+int adapt(mg_handle* h, double rn) {
+  bool promote = false;
+  const int to = adapt_target(h, rn, &promote);
+  if (promote) h->promoted = true;
   return switch_phase(h, to);
 }
 
@@ -1354,17 +1363,11 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
   for (it = 1; it <= max_iter; ++it) {
     const int before = h->phase;
     if (spec && h->cfg.precision == MG_PREC_ADAPTIVE) {
-      // would the policy switch?  evaluate it on a copy of the state first
-      const int to_before = h->phase;
-      const bool prom = h->promoted;
+      // would the policy switch?  After the speculative swap lv[0].u is the WRONG buffer to convert: drop the queued
+      // front part first, then switch from the untouched iterate
+      bool promote = false;
+      if (adapt_target(h, rn, &promote) != h->phase) undo_front();
       if ((rc = adapt(h, rn)) != MG_OK) return rc;
-      if (h->phase != to_before) {
-        // adapt() has converted the iterate out of lv[0].u -- which, after the speculative swap, is the WRONG buffer:
-        // redo it properly from the untouched iterate
-        h->phase = to_before; h->promoted = prom;
-        undo_front();
-        if ((rc = adapt(h, rn)) != MG_OK) return rc;
-      }
     } else {
       if ((rc = adapt(h, rn)) != MG_OK) return rc;               // solvers/multigrid.py:224-227
     }
