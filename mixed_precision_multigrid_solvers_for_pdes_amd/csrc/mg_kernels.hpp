@@ -1234,7 +1234,10 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
 // Invariants the driver maintains: boundary cells of u never change and both ping-pong buffers carry
 // them; coarse-level rhs boundary cells (injection of r = f) are written once when the rhs is set.
 // ============================================================================================
-constexpr int kFusedBlock = 512;
+#ifndef MG_FUSED_BLOCK
+#define MG_FUSED_BLOCK 512
+#endif
+constexpr int kFusedBlock = MG_FUSED_BLOCK;      // threads of a fused-leg workgroup (512: 3 workgroups / CU; 1024 measured slower, profiles/README.md)
 #ifndef MG_FUSED_TI
 #define MG_FUSED_TI 32
 #endif
