@@ -51,7 +51,7 @@ def cpu_baseline(n, levels, seconds_budget=12.0):
                 break
         threads = co.threads
         co.close()
-        return {"value": n * n * cycles / el / 1e6, "unit": "MDoF/s per V-cycle", "cores": threads, "kind": "port",
+        return {"value": n * n * cycles / el / 1e6, "unit": "MDoF/s", "cores": threads, "kind": "port",
                 "sample": f"{cycles} V(2,2) Jacobi cycles of the {n}^2 fp64 problem, C oracle (OpenMP, {threads} threads), {el:.1f} s"}
     except Exception as exc:                          # no compiler / OpenMP on this host
         mgo = O.MGOracle(n, n, max_levels=levels, cycle="V", smoother="jacobi", omega=0.8, jacobi_form="vectorized")
@@ -64,7 +64,7 @@ def cpu_baseline(n, levels, seconds_budget=12.0):
             el = time.time() - t0
             if el > seconds_budget or cycles >= 8:
                 break
-        return {"value": n * n * cycles / el / 1e6, "unit": "MDoF/s per V-cycle", "cores": 1, "kind": "port",
+        return {"value": n * n * cycles / el / 1e6, "unit": "MDoF/s", "cores": 1, "kind": "port",
                 "sample": f"{cycles} V(2,2) Jacobi cycles of the {n}^2 fp64 problem, NumPy oracle ({type(exc).__name__}: C oracle unavailable), {el:.1f} s"}
 
 
@@ -165,7 +165,7 @@ def main():
             "kernels": kern}
 
     out = {
-        "metric": "MDoF/s per V-cycle", "value": value, "unit": "MDoF/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "metric": "MDoF/s per V-cycle on 2D Poisson", "value": value, "unit": "MDoF/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32->f64 (adaptive)", "data": "synthetic",
         "config": {"workload": f"2D Poisson {n}^2 adaptive fp32->fp64 (switch_threshold=1e-6), V(2,2) weighted-Jacobi "
@@ -174,7 +174,7 @@ def main():
         "cycles_fp32": f32_cycles, "cycles_fp64": f64_cycles,
         "residual_initial": r0, "residual_first": hist[0], "residual_last": hist[-1],
         "iterations_to_1e-10_relative": its_rel, "iterations_to_1e-9_absolute": its_abs9,
-        "reference_cpu_captured": {"value": 0.83, "unit": "MDoF/s per V-cycle", "cores": 1, "kind": "reference",
+        "reference_cpu_captured": {"value": 0.83, "unit": "MDoF/s", "cores": 1, "kind": "reference",
                                    "sample": "the reference's own MultigridSolver (oracle configuration, NumPy Jacobi twin) at "
                                              "1025^2 fp64: 1.27 s/cycle on 1 core of the build container "
                                              "(tests/golden/large_1025.npz seconds_per_cycle); it cannot travel to the GPU box"},

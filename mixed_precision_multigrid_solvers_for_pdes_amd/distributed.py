@@ -804,7 +804,7 @@ def bench_main(args, rank, local_rank, world):
         value = NX * NY * K / dt / 1e6
         s0 = solvers["f64"]
         print(json.dumps({
-            "metric": "MDoF/s per V-cycle", "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": K, "warmup": W,
+            "metric": "MDoF/s per V-cycle on 2D Poisson", "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32->f64 (adaptive)", "data": "synthetic",
             "config": {"workload": f"2D Poisson {NX}x{NY} adaptive fp32->fp64 (switch_threshold={thr:g}), V(2,2) weighted-Jacobi "

@@ -1,0 +1,31 @@
+"""The bench line the driver parses: every key of the contract, on the line recorded with the final build
+(profiles/r01_bench_final.json = stdout of `python bench.py` on one MI355X)."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_recorded_bench_line_has_the_contract_keys():
+    line = open(os.path.join(ROOT, "profiles", "r01_bench_final.json")).read().strip()
+    assert "\n" not in line                                   # ONE JSON line
+    d = json.loads(line)
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert base["metric"].startswith(d["metric"]) and d["metric"].startswith("MDoF/s per V-cycle")   # BASELINE's headline clause
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4097 * 4097 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or 0.9 * r["compulsory_bytes_per_launch"] < r["traffic"] < 1.5 * r["compulsory_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"]
