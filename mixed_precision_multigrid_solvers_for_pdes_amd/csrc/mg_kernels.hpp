@@ -1253,14 +1253,16 @@ constexpr int kFusedBlock = MG_FUSED_BLOCK;      // threads of a fused-leg workg
 #ifndef MG_EXP_NO_STORE
 #define MG_EXP_NO_STORE 0
 #endif
-constexpr int kFusedTI = MG_FUSED_TI;      // tile rows of the fused legs (even: coarse rows sit on every other tile row)
+constexpr int kFusedTI = MG_FUSED_TI;      // tile rows of the fused legs on large levels (even: coarse rows sit on every other tile row)
+constexpr int kFusedTISmall = 16;          // ... on levels of <= ~1025^2 cells: twice the workgroups, half the critical path of a launch
+                                           // that is latency-bound anyway (4.4 vs 5.7 us per leg at 129^2-513^2)
 constexpr int kPostNone = 0, kPostRestrict = 1, kPostNorm = 2;
 
-template <typename T, int HALO> struct FusedShape {
+template <typename T, int HALO, int TI = kFusedTI> struct FusedShape {
   static constexpr int N = VecW<T>::N;
   static constexpr int TJ = kTileRowBytes / (int)sizeof(T);
   static constexpr int HV = (HALO + N - 1) / N;               // halo vectors per side
-  static constexpr int RI = kFusedTI + 2 * HALO;                   // region rows
+  static constexpr int RI = TI + 2 * HALO;                         // region rows
   static constexpr int RJ = TJ + 2 * HV * N;                  // region cols
   static constexpr int VPR = RJ / N;                          // vectors per region row
   static constexpr int RG = kFusedBlock / VPR;                // row groups
@@ -1283,14 +1285,14 @@ struct FusedArgs {
   int select, in_i_lo, in_i_hi, in_j_lo, in_j_hi;
 };
 
-template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM>
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int TI = kFusedTI>
 __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
     const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
     const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
     TX* __restrict__ rhs_coarse,          // POST == kPostRestrict: coarse rhs (dtype TX)
     double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 (interior cells) per block
     FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
-  using S = FusedShape<T, HALO>;
+  using S = FusedShape<T, HALO, TI>;
   constexpr int N = S::N;
   __shared__ __attribute__((aligned(16))) T bufA[S::ELEMS];
   __shared__ __attribute__((aligned(16))) T bufB[S::ELEMS];
@@ -1298,7 +1300,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
 
   const int L = xcd_remap(blockIdx.x, a.ntiles);
   const int ti = L / a.tiles_j, tj = L - ti * a.tiles_j;
-  const int i0 = 1 + ti * kFusedTI, j0 = tj * S::TJ;
+  const int i0 = 1 + ti * TI, j0 = tj * S::TJ;
   const int ri0 = i0 - HALO, rj0 = j0 - S::HV * N;           // global coords of region cell (0,0)
   if (a.select != 0) {
     const bool inner = ri0 >= a.in_i_lo && ri0 + S::RI <= a.in_i_hi && rj0 >= a.in_j_lo && rj0 + S::RJ <= a.in_j_hi;
@@ -1437,7 +1439,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   for (int k = 0; k < S::RPT; ++k) {
     const int r = r_base + k, gi = ri0 + r;
     if (!worker || r >= S::RI) continue;
-    if (!MG_EXP_NO_STORE && r >= HALO && r < HALO + kFusedTI && cv >= S::HV && cv < S::HV + S::TJ / N && gi < a.nx && gj0 < a.nyv)
+    if (!MG_EXP_NO_STORE && r >= HALO && r < HALO + TI && cv >= S::HV && cv < S::HV + S::TJ / N && gi < a.nx && gj0 < a.nyv)
       stg(out + (size_t)gi * a.ld + gj0, *reinterpret_cast<const Pack<T>*>(src + r * S::RJ + lc));
   }
 
@@ -1454,7 +1456,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
       if (r >= S::RI) break;
       const Pack<T> dn = (r + 1 < S::RI) ? *reinterpret_cast<const Pack<T>*>(src + (r + 1) * S::RJ + lc) : zero_pack<T>();
       Pack<T> o = f[k];
-      const bool in_tile = r >= HALO && r < HALO + kFusedTI && cv >= S::HV && cv < S::HV + S::TJ / N;
+      const bool in_tile = r >= HALO && r < HALO + TI && cv >= S::HV && cv < S::HV + S::TJ / N;
       const bool wanted = (POST == kPostRestrict) || in_tile;      // the norm only needs r on the tile itself
       if (!MG_EXP_NO_COMPUTE && wanted && r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
         const T left = src[r * S::RJ + lc - 1];
@@ -1485,7 +1487,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
 
   // ---- full-weighting restriction of the interior coarse cells that sit on this tile ---------------
   __syncthreads();
-  constexpr int CI = kFusedTI / 2, CJ = S::TJ / 2;          // coarse cells per tile
+  constexpr int CI = TI / 2, CJ = S::TJ / 2;                // coarse cells per tile
   for (int c = threadIdx.x; c < CI * CJ; c += kFusedBlock) {
     const int ci = c / CJ, cj = c - ci * CJ;
     const int fi = i0 + 1 + 2 * ci, fj = j0 + 2 * cj;  // i0 is odd: even fine rows are i0+1, i0+3, ...

@@ -288,13 +288,13 @@ void d_inject(int di, int dout, const void* fine, void* coarse, int ldf, int nxc
 
 // ------------------------------------------------------------------ fused legs ----------------
 struct LegGeom;
-template <typename T, int HALO>
+template <typename T, int HALO, int TI>
 mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int nxc, int nyc, int ldc, int poff) {
-  using S = mg::FusedShape<T, HALO>;
+  using S = mg::FusedShape<T, HALO, TI>;
   mg::FusedArgs a;
   a.nx = nx; a.ny = ny; a.ld = ld;
   a.nyv = std::min(ld, (ny + S::N - 1) / S::N * S::N);
-  const int tiles_i = (nx - 2 + mg::kFusedTI - 1) / mg::kFusedTI;
+  const int tiles_i = (nx - 2 + TI - 1) / TI;
   a.tiles_j = (ny - 1 + S::TJ - 1) / S::TJ;
   a.ntiles = tiles_i * a.tiles_j;
   a.nsweep = nsweep; a.use_div = use_div ? 1 : 0; a.colour_offset = poff & 1;
@@ -323,57 +323,76 @@ inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
 }
 
 // down leg: nsweep sweeps + residual + full-weighting restriction (interior coarse cells).  TX = coarse rhs dtype.
-template <typename T, typename TX, int SM>
-void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
+// Tile height by level size: 32 rows where the launch is bandwidth-bound, 16 where it is latency-bound (<= ~1025^2).
+inline bool small_tiles(const LegGeom& g) { return (long long)g.nx * g.ny <= 1100LL * 1100LL; }
+
+template <typename T, typename TX, int SM, int TI>
+void launch_down_ti(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
   constexpr int HALO = 2 * mg::sweep_halo(SM) + 2;
   const Coef c = coefs(g.hx, g.hy, g.sigma);
-  mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+  mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
   apply_sub(a, g);
   void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T);
-  if (zero_init) k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM>
-                            : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 0, SM>;
-  else k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 1, SM>
-                  : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 0, SM>;
+  if (zero_init) k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM, TI>
+                            : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 0, SM, TI>;
+  else k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 1, SM, TI>
+                  : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr,
                      (TX*)rhs_c, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+}
+template <typename T, typename TX, int SM>
+void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
+  if (small_tiles(g)) launch_down_ti<T, TX, SM, mg::kFusedTISmall>(u, rhs, out, rhs_c, g, zero_init, st);
+  else launch_down_ti<T, TX, SM, mg::kFusedTI>(u, rhs, out, rhs_c, g, zero_init, st);
 }
 
 // up leg: u += P e, nsweep sweeps, optional sum of r^2 over interior cells.  TX = coarse e dtype, TC = interpolation dtype.
 // returns the number of partials (0 without norm)
-template <typename T, typename TX, typename TC, int SM>
-int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm,
-              hipStream_t st) {
+template <typename T, typename TX, typename TC, int SM, int TI>
+int launch_up_ti(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm,
+                 hipStream_t st) {
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   if (norm) {
     constexpr int HALO = 2 * mg::sweep_halo(SM) + 1;
-    mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+    mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
     apply_sub(a, g);
-    auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM>
-                    : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 0, SM>;
+    auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM, TI>
+                    : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 0, SM, TI>;
     hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
                        (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
     return a.ntiles;
   }
   constexpr int HALO = 2 * mg::sweep_halo(SM);
-  mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
+  mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
   apply_sub(a, g);
-  auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM>
-                  : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 0, SM>;
+  auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM, TI>
+                  : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
                      (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
   return 0;
 }
+template <typename T, typename TX, typename TC, int SM>
+int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm,
+              hipStream_t st) {
+  return small_tiles(g) ? launch_up_ti<T, TX, TC, SM, mg::kFusedTISmall>(u, rhs, out, e_c, partials, g, norm, st)
+                        : launch_up_ti<T, TX, TC, SM, mg::kFusedTI>(u, rhs, out, e_c, partials, g, norm, st);
+}
 
 // plain multi-sweep smoothing (nsweep <= 2 per launch)
-template <typename T, int SM>
-void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
+template <typename T, int SM, int TI>
+void launch_sweeps_ti(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
   constexpr int HALO = 2 * mg::sweep_halo(SM);
   const Coef c = coefs(g.hx, g.hy, g.sigma);
-  const mg::FusedArgs a = fused_args<T, HALO>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, 0, 0, 0, g.poff);
-  auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM>
-                  : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 0, SM>;
+  const mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, 0, 0, 0, g.poff);
+  auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM, TI>
+                  : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr,
                      (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0);
+}
+template <typename T, int SM>
+void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
+  if (small_tiles(g)) launch_sweeps_ti<T, SM, mg::kFusedTISmall>(u, rhs, out, g, st);
+  else launch_sweeps_ti<T, SM, mg::kFusedTI>(u, rhs, out, g, st);
 }
 
 template <int SM>
@@ -1549,7 +1568,7 @@ int mg_dev_residual(int dtype, int nx, int ny, int ld, double hx, double hy, dou
 int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes) {
   CHECK_DEV(bytes && nx >= 1 && ny >= 1, "mg_dev_scratch_bytes: bad argument");
   // one fp64 partial per workgroup: <= 2048 for the grid-stride reductions, one per 32 x 512-byte tile for the up leg
-  const int64_t tiles = ((int64_t)(nx + mg::kFusedTI - 1) / mg::kFusedTI + 1) * ((int64_t)(ny + 63) / 64 + 1);
+  const int64_t tiles = ((int64_t)(nx + mg::kFusedTISmall - 1) / mg::kFusedTISmall + 1) * ((int64_t)(ny + 63) / 64 + 1);
   *bytes = (int64_t)sizeof(double) * std::max<int64_t>(2048, tiles);
   return MG_OK;
 }

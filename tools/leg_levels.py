@@ -20,7 +20,7 @@ eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), precision
 eng.set_rhs(rhs)
 eng.set_solution(None)
 eng.cycle(1)
-for level in range(0, 4):
+for level in range(0, min(7, eng.num_levels - 1)):
     m = eng.shapes[level][0]
     for dt, w in ((np.float32, 4), (np.float64, 8)):
         row = [f"level {level} {m:5d}^2 {np.dtype(dt).name}:"]
