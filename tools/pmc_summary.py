@@ -23,7 +23,7 @@ def classify(name):
     m = re.search(r"mg::jacobi_kernel<(float|double), 1,", name)
     if m:
         return f"jacobi_sweep_{'f32' if m.group(1) == 'float' else 'f64'}_{N}"
-    m = re.search(r"mg::fused_jacobi_kernel<(float|double), (\d+), (true|false), (\d), (true|false), \w+, \w+, 1, 0>", name)
+    m = re.search(r"mg::fused_jacobi_kernel<(float|double), (\d+), (true|false), (\d), (true|false), \w+, \w+, 1, 0(, \d+)?>", name)
     if not m:
         return None
     dt = "f32" if m.group(1) == "float" else "f64"
