@@ -83,6 +83,9 @@ typedef struct mg_config {
                                 cycles per level (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:583-652) */
   int32_t speculate;         /* with fused = 1 -- 1: mg_iterate / mg_solve queue the down leg of cycle k+1 while ||r_k||
                                 travels to the host (dropped if that norm ends the solve); 0: strictly one cycle at a time */
+  int32_t mixed_split;       /* MG_PREC_MIXED_LEVELS: first fp32 level; <= 0: num_levels / 2 (core/precision.py:351-357).
+                                Set by a caller whose handle is the lower part of a longer hierarchy (distributed.py: the
+                                replicated coarse levels below the decomposed ones keep the GLOBAL split) */
 } mg_config;
 
 typedef struct mg_stats {
@@ -130,7 +133,9 @@ int mg_iterate(mg_handle* h, double tol, int max_iter, double* hist, int hist_ca
  * design, parity unpinned -- a == 1 reproduces the constant-coefficient path bit for bit on dyadic grids).
  * `a` holds vertex values on the fine grid (host array, (nx, ny)); face values are arithmetic means; coarse
  * operators are re-discretised with `a` injected.  NULL switches back to the constant-coefficient operator.
- * Cycles of a variable-coefficient handle run one launch per operator (the fused legs are constant-coefficient). */
+ * Coarse levels take every 2^l-th vertex value, cast once from the caller's dtype.  Cycles run as fused legs too
+ * (coefficient tile staged with the iterate, face means kept in registers: 4.25 words / DoF per leg); fused = 0 keeps
+ * one launch per operator (4 words / DoF per sweep). */
 int mg_set_coefficient(mg_handle* h, const void* a_host_or_null, int host_dtype);
 
 /* Helmholtz shift: the operator of every level becomes A = coeff * (Laplacian_h - sigma I), i.e. -Laplacian + sigma
@@ -165,7 +170,8 @@ int mg_get_stream(mg_handle* h, void** stream);
  * (used by bench.py for the roofline line).  op: 0 jacobi sweep, 1 rbgs sweep (both colours),
  * 2 residual (store r), 3 residual+norm (no store), 4 restrict, 5 prolong+add, 6 whole cycle,
  * 7 fused down leg (2 sweeps + residual + restriction), 8 fused up leg (prolongation + 2 sweeps [+ norm on level 0]),
- * 9 two fused sweeps.
+ * 9 two fused sweeps, 10 the op-0 Jacobi sweep rotating over >= 3 independent {u, rhs, out} sets of > 768 MiB in total
+ * (allocated for the call), so that no launch finds its operands in the 256 MiB Infinity Cache: the HBM-proper figure.
  * dtype selects the precision of `level`'s arrays (must be allocated under cfg.precision). */
 int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg_ms);
 
@@ -233,6 +239,17 @@ int mg_dev_up_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, 
                   int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
                   const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
                   int nj_hi, void* scratch, double* sumsq_dev, void* stream);
+/* The same legs for the variable-coefficient operator A = coeff * div(a grad .): `acoef` holds the vertex values of a on
+ * this array (dtype / pitch of u, ghost zone included; NULL = the constant-coefficient legs above).  No reference
+ * counterpart; see mg_set_coefficient. */
+int mg_dev_down_leg_var(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
+                        int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
+                        const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream, int select, const int* inner_rect,
+                        const void* acoef);
+int mg_dev_up_leg_var(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
+                      int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
+                      const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
+                      int nj_hi, void* scratch, double* sumsq_dev, void* stream, const void* acoef);
 /* boundary ring of a coarse field := injected fine values, on the physical edges (`sides`) only */
 int mg_dev_inject_ring(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides, int ci_off,
                        int cj_off, const void* fine, void* coarse, void* stream);

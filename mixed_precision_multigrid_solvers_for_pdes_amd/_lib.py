@@ -30,7 +30,7 @@ class MgConfig(C.Structure):
         ("switch_threshold", C.c_double), ("memory_threshold_gb", C.c_double),
         ("adaptive_reference_rule", C.c_int32),
         ("device", C.c_int32), ("profile", C.c_int32), ("colour_offset", C.c_int32), ("fused", C.c_int32),
-        ("tail", C.c_int32), ("fmg_cycles", C.c_int32), ("speculate", C.c_int32),
+        ("tail", C.c_int32), ("fmg_cycles", C.c_int32), ("speculate", C.c_int32), ("mixed_split", C.c_int32),
     ]
 
 
@@ -94,6 +94,8 @@ SIGNATURES = {
     "mg_dev_convert": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mg_dev_down_leg": (_i, [_i] * 11 + [_d] * 4 + [_i] * 3 + [_vp] * 5 + [_i, C.POINTER(C.c_int)]),
     "mg_dev_up_leg": (_i, [_i] * 13 + [_d] * 4 + [_i] * 2 + [_vp] * 4 + [_i] * 5 + [_vp] * 3),
+    "mg_dev_down_leg_var": (_i, [_i] * 11 + [_d] * 4 + [_i] * 3 + [_vp] * 5 + [_i, C.POINTER(C.c_int), _vp]),
+    "mg_dev_up_leg_var": (_i, [_i] * 13 + [_d] * 4 + [_i] * 2 + [_vp] * 4 + [_i] * 5 + [_vp] * 4),
     "mg_dev_inject_ring": (_i, [_i] * 11 + [_vp] * 3),
     "mg_dev_scratch_bytes": (_i, [_i, _i, C.POINTER(C.c_int64)]),
     "mg_pitch_elems": (_i, [_i, _i, _pi]),

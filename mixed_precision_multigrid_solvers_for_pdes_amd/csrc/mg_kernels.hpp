@@ -493,6 +493,22 @@ __global__ __launch_bounds__(kBlock) void prolong_kernel(const TC_IN* __restrict
   }
 }
 
+// u[1:nx-1, 1:ny-1] = 0, boundary ring kept (the full-multigrid start on the finest level: Dirichlet data stay).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void zero_interior_kernel(T* __restrict__ u, int nx, int ny, int ld) {
+  constexpr int N = VecW<T>::N;
+  const int vpr = (ny + N - 1) / N;
+  const long long total = (long long)(nx - 2) * vpr;
+  for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
+    const int i = 1 + (int)(v / vpr), j0 = (int)(v % vpr) * N;
+    Pack<T> p = ldg(u + (size_t)i * ld + j0);
+#pragma unroll
+    for (int e = 0; e < N; ++e)
+      if (j0 + e >= 1 && j0 + e < ny - 1) p.v[e] = T(0);
+    stg(u + (size_t)i * ld + j0, p);
+  }
+}
+
 // Element-wise precision switch (reference: core/precision.py:106-134 `astype`).
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(kBlock) void convert_kernel(const TIN* __restrict__ in, TOUT* __restrict__ out, int nx,
@@ -582,6 +598,7 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
 //   evaluated from snapshot k, and when it meets the tolerance (or k == maxit) snapshot k IS the result
 //   (the few speculative updates of later sweeps are dropped).  Returns the number of sweeps.
 // --------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T rhx2_of(T h2) { return T(1) / h2; }
 constexpr int kPipeCells = 81;     // up to 9 x 9
 constexpr int kPipeSlots = 9;      // >= (dmax - 2) / 2 + 2 for 9 x 9 (dmax = 14)
 
@@ -602,9 +619,12 @@ template <int CTRL> __device__ __forceinline__ float dpp_row_move(float x) {
 // register, and because a lane on diagonal d is always floor((6 - d) / 2) sweeps ahead of the sweep under test, the
 // snapshot the stop test needs sits at a per-lane constant depth.  Same expressions, same sweep / stop semantics as
 // the LDS version below (the stop test sums its nine squares in a different lane order).
-template <typename T>
+// VAR: variable coefficient (vertex values in `sa`, LDS): every lane keeps the four face means and the diagonal of its
+// cell in registers; the arithmetic is coarse_lexgs_kernel's variable-coefficient branch.
+template <typename T, bool VAR = false>
 __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf, T hx2, T hy2, T diag, T coeff, T omega,
-                                   T one_m_omega, bool exact, double hxhy, double tol, int maxit, int lane) {
+                                   T one_m_omega, bool exact, double hxhy, double tol, int maxit, int lane,
+                                   const T* __restrict__ sa = nullptr, T sigma = T(0)) {
   constexpr int ny = 5;
   const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
   double ring = 0.0;
@@ -621,6 +641,12 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
   // ring neighbours (constant over the solve); interior neighbours are fetched from the adjacent lanes every step
   const bool up_ring = gi == 1, dn_ring = gi == 3, lf_ring = gj == 1, rt_ring = gj == 3;
   const T up_c = su[g - ny], dn_c = su[g + ny], lf_c = su[g - 1], rt_c = su[g + 1];
+  T aip = T(1), aim = T(1), ajp = T(1), ajm = T(1), Dv = diag;
+  if (VAR) {
+    const T ac = sa[g];
+    aip = T(0.5) * (ac + sa[g + ny]); aim = T(0.5) * (ac + sa[g - ny]); ajp = T(0.5) * (ac + sa[g + 1]); ajm = T(0.5) * (ac + sa[g - 1]);
+    Dv = (exact ? (aip + aim) * rhx2 + (ajp + ajm) * rhy2 : (aip + aim) / hx2 + (ajp + ajm) / hy2) + sigma;
+  }
   T h0 = uv, h1 = uv, h2 = uv;                    // the lane's last three sweep values, newest first
   int tnext = 2 + d, knext = 1;
   int kc = 1, tdone = 2 + 6;
@@ -636,10 +662,10 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
       const T n_lf = dpp_row_move<0x111>(uv);     // row_shr:1
       const T n_rt = dpp_row_move<0x101>(uv);     // row_shl:1
       const T up = up_ring ? up_c : n_up, dn = dn_ring ? dn_c : n_dn, lf = lf_ring ? lf_c : n_lf, rt = rt_ring ? rt_c : n_rt;
-      const T sx = dn + up, sy = rt + lf;
+      const T sx = VAR ? aip * dn + aim * up : dn + up, sy = VAR ? ajp * rt + ajm * lf : rt + lf;
       const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
       const T num = fv + nb;
-      const T un = exact ? num * rdiag : num / diag;
+      const T un = VAR ? num / Dv : (exact ? num * rdiag : num / diag);
       const T nv = one_m_omega * uv + omega * un;
       if (mine && t == tnext && knext <= maxit) {
         uv = nv;
@@ -654,8 +680,8 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
       const T n_up = dpp_row_move<0x113>(snap), n_dn = dpp_row_move<0x103>(snap);
       const T n_lf = dpp_row_move<0x111>(snap), n_rt = dpp_row_move<0x101>(snap);
       const T up = up_ring ? up_c : n_up, dn = dn_ring ? dn_c : n_dn, lf = lf_ring ? lf_c : n_lf, rt = rt_ring ? rt_c : n_rt;
-      const T sx = dn + up, sy = rt + lf;
-      const T rv = fv - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap * diag);
+      const T sx = VAR ? aip * dn + aim * up : dn + up, sy = VAR ? ajp * rt + ajm * lf : rt + lf;
+      const T rv = fv - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap * (VAR ? Dv : diag));
       double acc = mine ? (double)rv * (double)rv : 0.0;
       acc = wave_first(wave_reduce_sum(acc));
       if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
@@ -672,11 +698,17 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
   return sweeps;
 }
 
-template <typename T>
+template <typename T, bool VAR = false>
 __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* __restrict__ hist, int nx, int ny,
                                T hx2, T hy2, T diag, T coeff, T omega, T one_m_omega, bool exact, double hxhy,
-                               double tol, int maxit, int lane) {
-  if (nx == 5 && ny == 5) return lexgs_pipelined_5x5<T>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, exact, hxhy, tol, maxit, lane);
+                               double tol, int maxit, int lane, const T* __restrict__ sa = nullptr, T sigma = T(0)) {
+  if (nx == 5 && ny == 5) return lexgs_pipelined_5x5<T, VAR>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, exact, hxhy, tol, maxit, lane, sa, sigma);
+  // face means and diagonal of cell c (variable coefficient; coarse_lexgs_kernel's expressions)
+  auto faces = [&](int c, T& aip, T& aim, T& ajp, T& ajm, T& Dv) {
+    const T ac = sa[c];
+    aip = T(0.5) * (ac + sa[c + ny]); aim = T(0.5) * (ac + sa[c - ny]); ajp = T(0.5) * (ac + sa[c + 1]); ajm = T(0.5) * (ac + sa[c - 1]);
+    Dv = (exact ? (aip + aim) * rhx2_of(hx2) + (ajp + ajm) * rhx2_of(hy2) : (aip + aim) / hx2 + (ajp + ajm) / hy2) + sigma;
+  };
   const int ncell = nx * ny, dmax = nx + ny - 4;
   const int H = (dmax - 1) / 2 + 2;
   const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
@@ -700,6 +732,8 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
     const bool interior = c < ncell && ci >= 1 && ci <= nx - 2 && cj >= 1 && cj <= ny - 2;
     const T fv = interior ? sf[c] : T(0);
     T uv = interior ? su[c] : T(0);
+    T aip = T(1), aim = T(1), ajp = T(1), ajm = T(1), Dv = diag;
+    if (VAR && interior) faces(c, aip, aim, ajp, ajm, Dv);
     int tnext = 2 + ci + cj;            // time of this cell's next update: 2k + d with k = 1
     int knext = 1;
     T* hslot = hist + c;                // snapshot slot of sweep knext (slot index knext % H, advanced incrementally)
@@ -710,10 +744,11 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
     int tdone = 2 + dmax;               // time at which sweep kc is complete
     for (int t = 4;; ++t) {
       if (interior && t == tnext && knext <= maxit) {
-        const T sx = su[c + ny] + su[c - ny], sy = su[c + 1] + su[c - 1];
+        const T sx = VAR ? aip * su[c + ny] + aim * su[c - ny] : su[c + ny] + su[c - ny];
+        const T sy = VAR ? ajp * su[c + 1] + ajm * su[c - 1] : su[c + 1] + su[c - 1];
         const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
         const T num = fv + nb;
-        const T un = exact ? num * rdiag : num / diag;
+        const T un = VAR ? num / Dv : (exact ? num * rdiag : num / diag);
         uv = one_m_omega * uv + omega * un;
         su[c] = uv;
         *hslot = uv;
@@ -725,8 +760,9 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
       if (t == tdone) {
         double acc = 0.0;
         if (interior) {
-          const T sx = snap[c + ny] + snap[c - ny], sy = snap[c + 1] + snap[c - 1];
-          const T rv = fv - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap[c] * diag);
+          const T sx = VAR ? aip * snap[c + ny] + aim * snap[c - ny] : snap[c + ny] + snap[c - ny];
+          const T sy = VAR ? ajp * snap[c + 1] + ajm * snap[c - 1] : snap[c + 1] + snap[c - 1];
+          const T rv = fv - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap[c] * (VAR ? Dv : diag));
           acc = (double)rv * (double)rv;
         }
         acc = wave_reduce_sum(acc);
@@ -752,10 +788,13 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
       if (td & 1) continue;
       const int k = td >> 1;
       if (k < 1 || k > maxit) continue;
-      const T sx = su[c + ny] + su[c - ny], sy = su[c + 1] + su[c - 1];
+      T aip = T(1), aim = T(1), ajp = T(1), ajm = T(1), Dv = diag;
+      if (VAR) faces(c, aip, aim, ajp, ajm, Dv);
+      const T sx = VAR ? aip * su[c + ny] + aim * su[c - ny] : su[c + ny] + su[c - ny];
+      const T sy = VAR ? ajp * su[c + 1] + ajm * su[c - 1] : su[c + 1] + su[c - 1];
       const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
       const T num = sf[c] + nb;
-      const T un = exact ? num * rdiag : num / diag;
+      const T un = VAR ? num / Dv : (exact ? num * rdiag : num / diag);
       const T v = one_m_omega * su[c] + omega * un;
       su[c] = v;
       hist[(k % H) * ncell + c] = v;
@@ -769,8 +808,11 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
       for (int c = lane; c < ncell; c += 64) {
         const int i = c / ny, j = c - i * ny;
         if (i < 1 || i > nx - 2 || j < 1 || j > ny - 2) continue;
-        const T sx = snap[c + ny] + snap[c - ny], sy = snap[c + 1] + snap[c - 1];
-        const T rv = sf[c] - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap[c] * diag);
+        T aip = T(1), aim = T(1), ajp = T(1), ajm = T(1), Dv = diag;
+        if (VAR) faces(c, aip, aim, ajp, ajm, Dv);
+        const T sx = VAR ? aip * snap[c + ny] + aim * snap[c - ny] : snap[c + ny] + snap[c - ny];
+        const T sy = VAR ? ajp * snap[c + 1] + ajm * snap[c - 1] : snap[c + 1] + snap[c - 1];
+        const T rv = sf[c] - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap[c] * (VAR ? Dv : diag));
         acc += (double)rv * (double)rv;
       }
       acc = wave_reduce_sum(acc);
@@ -949,14 +991,15 @@ __global__ __launch_bounds__(kBlock) void varcoef_kernel(const T* u_in, const T*
   }
 }
 
-// full injection fine -> coarse (coefficient field of the re-discretised coarse operators)
+// full injection fine -> coarse with a stride (coefficient field of the re-discretised coarse operators: level l takes
+// every 2^l-th vertex value of the fine field, cast to the level's precision)
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(kBlock) void inject_kernel(const TIN* __restrict__ fine, TOUT* __restrict__ coarse, int ldf,
-                                                        int nxc, int nyc, int ldc) {
+                                                        int nxc, int nyc, int ldc, int stride) {
   const long long total = (long long)nxc * nyc;
   for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
     const int ic = (int)(v / nyc), jc = (int)(v - (long long)ic * nyc);
-    coarse[(size_t)ic * ldc + jc] = (TOUT)fine[(size_t)(2 * ic) * ldf + 2 * jc];
+    coarse[(size_t)ic * ldc + jc] = (TOUT)fine[(size_t)(stride * ic) * ldf + (size_t)stride * jc];
   }
 }
 
@@ -983,33 +1026,58 @@ struct TailArgs {
   int smoother;                // kSmJacobi / kSmRbgs
   int colour_offset;
   double omega, coeff, tol;
+  double sigma;                // Helmholtz shift of the variable-coefficient diagonal (constant path: folded into diag)
   TailLevel lv[kTailMaxLevels];
+  const void* a_lv[kTailMaxLevels];   // VAR: the coefficient field of every tail level in HBM (dtype of that level)
+  int a_ld[kTailMaxLevels];
 };
 
+// variable coefficient: the relaxed value of cell idx from the vertex values `A` (varcoef_kernel's expressions)
 template <typename T>
+__device__ __forceinline__ T tail_var_un(const T* __restrict__ src, const T* __restrict__ A, T fv, int idx, int ny, T ihx2, T ihy2,
+                                         T sigma) {
+  const T ac = A[idx];
+  const T aip = T(0.5) * (ac + A[idx + ny]), aim = T(0.5) * (ac + A[idx - ny]);
+  const T ajp = T(0.5) * (ac + A[idx + 1]), ajm = T(0.5) * (ac + A[idx - 1]);
+  const T sx = aip * src[idx + ny] + aim * src[idx - ny], sy = ajp * src[idx + 1] + ajm * src[idx - 1];
+  const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+  return (fv + (ihx2 * sx + ihy2 * sy)) / ((sigma != T(0)) ? D0 + sigma : D0);
+}
+
+template <typename T, bool VAR>
 __device__ __forceinline__ void tail_sweep(const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ f,
-                                           const TailLevel& L, T omega, T one_m_omega) {
+                                           const TailLevel& L, T omega, T one_m_omega, const T* __restrict__ A, T sigma) {
   const T ihx2 = (T)L.ihx2, ihy2 = (T)L.ihy2, invD = (T)L.invD, D = (T)L.diag;
   const int ny = L.ny, ni = L.nx - 2, nj = ny - 2;
   for (int c = threadIdx.x; c < ni * nj; c += kTailBlock) {
     const int i = 1 + c / nj, j = 1 + c % nj, idx = i * ny + j;
-    const T nb = ihx2 * (src[idx + ny] + src[idx - ny]) + ihy2 * (src[idx + 1] + src[idx - 1]);
-    const T un = L.use_div ? (f[idx] + nb) / D : (f[idx] + nb) * invD;
+    T un;
+    if (VAR) {
+      un = tail_var_un<T>(src, A, f[idx], idx, ny, ihx2, ihy2, sigma);
+    } else {
+      const T nb = ihx2 * (src[idx + ny] + src[idx - ny]) + ihy2 * (src[idx + 1] + src[idx - 1]);
+      un = L.use_div ? (f[idx] + nb) / D : (f[idx] + nb) * invD;
+    }
     dst[idx] = one_m_omega * src[idx] + omega * un;
   }
 }
 
 // one colour pass of red-black GS, in place (solvers/smoothers.py:183-205)
-template <typename T>
+template <typename T, bool VAR>
 __device__ __forceinline__ void tail_rb_pass(T* __restrict__ u, const T* __restrict__ f, const TailLevel& L, T omega,
-                                             T one_m_omega, int colour, int poff) {
+                                             T one_m_omega, int colour, int poff, const T* __restrict__ A, T sigma) {
   const T ihx2 = (T)L.ihx2, ihy2 = (T)L.ihy2, invD = (T)L.invD, D = (T)L.diag;
   const int ny = L.ny, ni = L.nx - 2, nj = ny - 2;
   for (int c = threadIdx.x; c < ni * nj; c += kTailBlock) {
     const int i = 1 + c / nj, j = 1 + c % nj, idx = i * ny + j;
     if (((i + j + poff) & 1) != colour) continue;
-    const T nb = ihx2 * (u[idx + ny] + u[idx - ny]) + ihy2 * (u[idx + 1] + u[idx - 1]);
-    const T un = L.use_div ? (f[idx] + nb) / D : (f[idx] + nb) * invD;
+    T un;
+    if (VAR) {
+      un = tail_var_un<T>(u, A, f[idx], idx, ny, ihx2, ihy2, sigma);
+    } else {
+      const T nb = ihx2 * (u[idx + ny] + u[idx - ny]) + ihy2 * (u[idx + 1] + u[idx - 1]);
+      un = L.use_div ? (f[idx] + nb) / D : (f[idx] + nb) * invD;
+    }
     u[idx] = one_m_omega * u[idx] + omega * un;
   }
 }
@@ -1023,22 +1091,25 @@ __device__ long long g_tail_trace[64];     // timing experiment: s_memtime at en
 #else
 #define TAIL_STAMP(k) do { } while (0)
 #endif
-template <typename T, typename TCO, typename TC>
+template <typename T, typename TCO, typename TC, bool VAR = false>
 __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __restrict__ rhs_top, T* __restrict__ u_top,
                                                                  const int* __restrict__ ops, TailArgs a, int zero_top,
                                                                  int* __restrict__ sweeps_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pool[];
   TAIL_STAMP(0);
   const int last = a.nlev - 1;
-  const T omega = (T)a.omega, one_m_omega = (T)(1.0 - a.omega), coeff = (T)a.coeff;
-  // per level: two iterate buffers (ping-pong) and the rhs; the last level holds {u, rhs} in TCO
+  const T omega = (T)a.omega, one_m_omega = (T)(1.0 - a.omega), coeff = (T)a.coeff, sigma = (T)a.sigma;
+  // per level: two iterate buffers (ping-pong), the rhs [and the coefficient: VAR]; the last level holds {u, rhs [, a]} in TCO
   auto Ubuf = [&](int l, int which) -> T* { return reinterpret_cast<T*>(pool + a.lv[l].off) + (size_t)which * a.lv[l].nx * a.lv[l].ny; };
   auto Fbuf = [&](int l) -> T* { return reinterpret_cast<T*>(pool + a.lv[l].off) + (size_t)2 * a.lv[l].nx * a.lv[l].ny; };
+  auto Abuf = [&](int l) -> T* { return VAR ? reinterpret_cast<T*>(pool + a.lv[l].off) + (size_t)3 * a.lv[l].nx * a.lv[l].ny : nullptr; };
   TCO* const Ulast = reinterpret_cast<TCO*>(pool + a.lv[last].off);
   TCO* const Flast = Ulast + a.lv[last].nx * a.lv[last].ny;
+  TCO* const Alast = Flast + a.lv[last].nx * a.lv[last].ny;                 // VAR only
+  TCO* const Hist = VAR ? Alast + a.lv[last].nx * a.lv[last].ny : Alast;    // snapshot ring of the pipelined coarsest solve
 
   {   // zero the pool (rings of every iterate buffer stay zero for the whole launch), then load the top level
-    const int quads = (a.lv[last].off + 2 * a.lv[last].nx * a.lv[last].ny * (int)sizeof(TCO) + 15) / 16;
+    const int quads = (a.lv[last].off + (VAR ? 3 : 2) * a.lv[last].nx * a.lv[last].ny * (int)sizeof(TCO) + 15) / 16;
     int4* w = reinterpret_cast<int4*>(pool);
     for (int c = threadIdx.x; c < quads; c += kTailBlock) w[c] = make_int4(0, 0, 0, 0);
   }
@@ -1051,6 +1122,16 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
       const int i = c / L0.ny, j = c - i * L0.ny;
       f0[c] = rhs_top[(size_t)i * a.ld_top + j];
       if (!zero_top && i >= 1 && i < L0.nx - 1 && j >= 1 && j < L0.ny - 1) u0[c] = u_top[(size_t)i * a.ld_top + j];
+    }
+    if (VAR) {      // the coefficient of every tail level (a few KB, L2-resident between visits)
+      for (int l = 0; l <= last; ++l) {
+        const TailLevel& Ll = a.lv[l];
+        for (int c = threadIdx.x; c < Ll.nx * Ll.ny; c += kTailBlock) {
+          const int i = c / Ll.ny, j = c - i * Ll.ny;
+          if (l == last) Alast[c] = reinterpret_cast<const TCO*>(a.a_lv[l])[(size_t)i * a.a_ld[l] + j];
+          else Abuf(l)[c] = reinterpret_cast<const T*>(a.a_lv[l])[(size_t)i * a.a_ld[l] + j];
+        }
+      }
     }
   }
   __syncthreads();
@@ -1073,11 +1154,11 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
       for (int s = 0; s < a.pre; ++s) {
         if (a.smoother == kSmRbgs) {
           for (int colour = 0; colour < 2; ++colour) {
-            tail_rb_pass<T>(Ubuf(l, (cur >> l) & 1), Fbuf(l), L, omega, one_m_omega, colour, a.colour_offset);
+            tail_rb_pass<T, VAR>(Ubuf(l, (cur >> l) & 1), Fbuf(l), L, omega, one_m_omega, colour, a.colour_offset, Abuf(l), sigma);
             __syncthreads();
           }
         } else {
-          tail_sweep<T>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega);
+          tail_sweep<T, VAR>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega, Abuf(l), sigma);
           cur ^= (1u << l);
           __syncthreads();
         }
@@ -1088,9 +1169,20 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
       const T* f = Fbuf(l);
       {
         const T ihx2 = (T)L.ihx2, ihy2 = (T)L.ihy2, D = (T)L.diag;
+        const T* A = Abuf(l);
         for (int c = threadIdx.x; c < ni * nj; c += kTailBlock) {
           const int idx = (1 + c / nj) * ny + 1 + c % nj;
-          const T au = coeff * (((u[idx + ny] + u[idx - ny]) * ihx2 + (u[idx + 1] + u[idx - 1]) * ihy2) - u[idx] * D);
+          T au;
+          if (VAR) {
+            const T ac = A[idx];
+            const T aip = T(0.5) * (ac + A[idx + ny]), aim = T(0.5) * (ac + A[idx - ny]);
+            const T ajp = T(0.5) * (ac + A[idx + 1]), ajm = T(0.5) * (ac + A[idx - 1]);
+            const T sx = aip * u[idx + ny] + aim * u[idx - ny], sy = ajp * u[idx + 1] + ajm * u[idx - 1];
+            const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+            au = coeff * ((sx * ihx2 + sy * ihy2) - u[idx] * ((sigma != T(0)) ? D0 + sigma : D0));
+          } else {
+            au = coeff * (((u[idx + ny] + u[idx - ny]) * ihx2 + (u[idx + 1] + u[idx - 1]) * ihy2) - u[idx] * D);
+          }
           r[idx] = f[idx] - au;
         }
       }
@@ -1127,9 +1219,9 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
           __builtin_amdgcn_wave_barrier();
         }
         if (nx * ny <= kPipeCells && (nx + ny - 5) / 2 + 2 <= kPipeSlots) {
-          TCO* hist = Flast + nx * ny;       // kPipeSlots snapshots behind the last level's arrays
-          const int sw = lexgs_pipelined<TCO>(Ulast, Flast, hist, nx, ny, hx2, hy2, diag, cf, TCO(1), TCO(0), exact, L.hxhy,
-                                              a.tol, a.maxit, lane);
+          // kPipeSlots snapshots behind the last level's arrays
+          const int sw = lexgs_pipelined<TCO, VAR>(Ulast, Flast, Hist, nx, ny, hx2, hy2, diag, cf, TCO(1), TCO(0), exact, L.hxhy,
+                                                   a.tol, a.maxit, lane, VAR ? Alast : nullptr, (TCO)a.sigma);
           if (lane == 0 && sweeps_out) *sweeps_out = sw;
         } else {
         int it = 0;
@@ -1138,10 +1230,18 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
             const int ilo = max(1, sdiag - (ny - 2)), ihi = min(nx - 2, sdiag - 1);
             for (int i = ilo + lane; i <= ihi; i += 64) {
               const int idx = i * ny + (sdiag - i);
-              const TCO sx = su[idx + ny] + su[idx - ny], sy = su[idx + 1] + su[idx - 1];
+              TCO aip = TCO(1), aim = TCO(1), ajp = TCO(1), ajm = TCO(1), Dv = diag;
+              if (VAR) {
+                const TCO ac = Alast[idx];
+                aip = TCO(0.5) * (ac + Alast[idx + ny]); aim = TCO(0.5) * (ac + Alast[idx - ny]);
+                ajp = TCO(0.5) * (ac + Alast[idx + 1]); ajm = TCO(0.5) * (ac + Alast[idx - 1]);
+                Dv = (exact ? (aip + aim) * rhx2 + (ajp + ajm) * rhy2 : (aip + aim) / hx2 + (ajp + ajm) / hy2) + (TCO)a.sigma;
+              }
+              const TCO sx = VAR ? aip * su[idx + ny] + aim * su[idx - ny] : su[idx + ny] + su[idx - ny];
+              const TCO sy = VAR ? ajp * su[idx + 1] + ajm * su[idx - 1] : su[idx + 1] + su[idx - 1];
               const TCO nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
               const TCO num = sf[idx] + nb;
-              const TCO un = exact ? num * rdiag : num / diag;
+              const TCO un = VAR ? num / Dv : (exact ? num * rdiag : num / diag);
               su[idx] = TCO(0) * su[idx] + TCO(1) * un;      // omega = 1: (1-w)*u + w*un, as the reference evaluates it
             }
             __builtin_amdgcn_wave_barrier();
@@ -1151,8 +1251,16 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
             const int i = c / ny, j = c - i * ny;
             TCO rv = sf[c];
             if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1) {
-              const TCO sx = su[c + ny] + su[c - ny], sy = su[c + 1] + su[c - 1];
-              rv = rv - cf * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - su[c] * diag);
+              TCO aip = TCO(1), aim = TCO(1), ajp = TCO(1), ajm = TCO(1), Dv = diag;
+              if (VAR) {
+                const TCO ac = Alast[c];
+                aip = TCO(0.5) * (ac + Alast[c + ny]); aim = TCO(0.5) * (ac + Alast[c - ny]);
+                ajp = TCO(0.5) * (ac + Alast[c + 1]); ajm = TCO(0.5) * (ac + Alast[c - 1]);
+                Dv = (exact ? (aip + aim) * rhx2 + (ajp + ajm) * rhy2 : (aip + aim) / hx2 + (ajp + ajm) / hy2) + (TCO)a.sigma;
+              }
+              const TCO sx = VAR ? aip * su[c + ny] + aim * su[c - ny] : su[c + ny] + su[c - ny];
+              const TCO sy = VAR ? ajp * su[c + 1] + ajm * su[c - 1] : su[c + 1] + su[c - 1];
+              rv = rv - cf * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - su[c] * Dv);
             }
             acc += (double)rv * (double)rv;
           }
@@ -1190,11 +1298,11 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
       for (int s = 0; s < a.post; ++s) {
         if (a.smoother == kSmRbgs) {
           for (int colour = 0; colour < 2; ++colour) {
-            tail_rb_pass<T>(Ubuf(l, (cur >> l) & 1), Fbuf(l), L, omega, one_m_omega, colour, a.colour_offset);
+            tail_rb_pass<T, VAR>(Ubuf(l, (cur >> l) & 1), Fbuf(l), L, omega, one_m_omega, colour, a.colour_offset, Abuf(l), sigma);
             __syncthreads();
           }
         } else {
-          tail_sweep<T>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega);
+          tail_sweep<T, VAR>(Ubuf(l, (cur >> l) & 1), Ubuf(l, ((cur >> l) & 1) ^ 1), Fbuf(l), L, omega, one_m_omega, Abuf(l), sigma);
           cur ^= (1u << l);
           __syncthreads();
         }
@@ -1285,13 +1393,21 @@ struct FusedArgs {
   int select, in_i_lo, in_i_hi, in_j_lo, in_j_hi;
 };
 
-template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int TI = kFusedTI>
+// VAR: the variable-coefficient operator A = coeff * div(a grad .) (see varcoef_kernel above for the discretisation and
+// its association order, which the stages below repeat).  A thread owns the same RPT x N cells in every stage, so the
+// face coefficients of its cells -- (RPT + 1) x N vertical, RPT x (N + 1) horizontal arithmetic means of the vertex values
+// -- are formed ONCE from an LDS-staged tile of `a` and then live in registers: the legs still move u, rhs and the
+// transfer operand once, plus `a` once: 4.25 w / DoF per leg against 4 w per sweep with one launch per operator.
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int TI = kFusedTI,
+          bool VAR = false>
 __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
     const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
     const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
     TX* __restrict__ rhs_coarse,          // POST == kPostRestrict: coarse rhs (dtype TX)
     double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 (interior cells) per block
-    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
+    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff,
+    const T* __restrict__ acoef,          // VAR: vertex values of the diffusion coefficient (same shape / pitch as u)
+    T sigma) {                            // VAR: Helmholtz shift added to the per-cell diagonal (constant path: folded into D)
   using S = FusedShape<T, HALO, TI>;
   constexpr int N = S::N;
   __shared__ __attribute__((aligned(16))) T bufA[S::ELEMS];
@@ -1314,6 +1430,54 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   const int gj0 = rj0 + cv * N;
   const int lc = cv * N;
   const int r_base = rg * S::RPT;
+
+  // ---- VAR: face coefficients of this thread's cells into registers (vertex values staged through bufA) ----------
+  constexpr int AVK = VAR ? S::RPT + 1 : 1, AVN = VAR ? N : 1, AHK = VAR ? S::RPT : 1, AHN = VAR ? N + 1 : 1;
+  T av[AVK][AVN];     // av[k][e]: face between rows r_base + k - 1 and r_base + k     (a(i-1/2) of row k, a(i+1/2) of row k - 1)
+  T ah[AHK][AHN];     // ah[k][e]: face between columns lc + e - 1 and lc + e of row r_base + k
+  if (VAR) {
+#pragma unroll
+    for (int k = 0; k < S::RPT; ++k) {
+      const int r = r_base + k, gi = ri0 + r;
+      if (!worker || r >= S::RI) continue;
+      Pack<T> p = zero_pack<T>();
+      if (gi >= 0 && gi < a.nx && gj0 >= 0 && gj0 < a.nyv) p = ldg(acoef + (size_t)gi * a.ld + gj0);
+      *reinterpret_cast<Pack<T>*>(bufA + r * S::RJ + lc) = p;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < AVK; ++k)
+#pragma unroll
+      for (int e = 0; e < AVN; ++e) av[k][e] = T(0);
+#pragma unroll
+    for (int k = 0; k < AHK; ++k)
+#pragma unroll
+      for (int e = 0; e < AHN; ++e) ah[k][e] = T(0);
+    if (worker && r_base < S::RI) {
+      Pack<T> up = (r_base >= 1) ? *reinterpret_cast<const Pack<T>*>(bufA + (r_base - 1) * S::RJ + lc) : zero_pack<T>();
+      Pack<T> mid = *reinterpret_cast<const Pack<T>*>(bufA + r_base * S::RJ + lc);
+#pragma unroll
+      for (int k = 0; k < S::RPT; ++k) {
+        const int r = r_base + k;
+        if (r >= S::RI) break;
+        const Pack<T> dn = (r + 1 < S::RI) ? *reinterpret_cast<const Pack<T>*>(bufA + (r + 1) * S::RJ + lc) : zero_pack<T>();
+        if (r >= 1 && r < S::RI - 1) {          // region-edge rows are never updated: their faces are not needed
+          const T left = bufA[r * S::RJ + lc - 1];
+          const T right = bufA[r * S::RJ + lc + N];
+#pragma unroll
+          for (int e = 0; e < N; ++e) {
+            av[VAR ? k : 0][VAR ? e : 0] = T(0.5) * (mid.v[e] + up.v[e]);
+            av[VAR ? k + 1 : 0][VAR ? e : 0] = T(0.5) * (mid.v[e] + dn.v[e]);
+            ah[VAR ? k : 0][VAR ? e : 0] = T(0.5) * (mid.v[e] + ((e == 0) ? left : mid.v[e > 0 ? e - 1 : 0]));
+          }
+          ah[VAR ? k : 0][VAR ? N : 0] = T(0.5) * (mid.v[N - 1] + right);
+        }
+        up = mid;
+        mid = dn;
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- load: rhs strip into registers, u (+ P e) into LDS --------------------------------------
   // PROLONG: the (RI/2 + 2) x (RJ/2 + 2) patch of coarse values under the region is staged once, coalesced, in
@@ -1388,8 +1552,17 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
           for (int e = 0; e < N; ++e) {
             const T w = (e == 0) ? left : mid.v[e - 1];
             const T ea = (e == N - 1) ? right : mid.v[e + 1];
-            const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
-            const T un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
+            T un;
+            if (VAR) {
+              const T aip = av[VAR ? k + 1 : 0][VAR ? e : 0], aim = av[VAR ? k : 0][VAR ? e : 0];
+              const T ajp = ah[VAR ? k : 0][VAR ? e + 1 : 0], ajm = ah[VAR ? k : 0][VAR ? e : 0];
+              const T sx = aip * dn.v[e] + aim * up.v[e], sy = ajp * ea + ajm * w;
+              const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+              un = (f[k].v[e] + (ihx2 * sx + ihy2 * sy)) / ((sigma != T(0)) ? D0 + sigma : D0);
+            } else {
+              const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
+              un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
+            }
             const T res = one_m_omega * mid.v[e] + omega * un;
             const int gj = gj0 + e;
             if (gj >= 1 && gj < a.ny - 1 && (((gi + gj + a.colour_offset) & 1) == colour)) o.v[e] = res;
@@ -1417,8 +1590,17 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
           for (int e = 0; e < N; ++e) {
             const T w = (e == 0) ? left : mid.v[e - 1];
             const T ea = (e == N - 1) ? right : mid.v[e + 1];
-            const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
-            const T un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
+            T un;
+            if (VAR) {
+              const T aip = av[VAR ? k + 1 : 0][VAR ? e : 0], aim = av[VAR ? k : 0][VAR ? e : 0];
+              const T ajp = ah[VAR ? k : 0][VAR ? e + 1 : 0], ajm = ah[VAR ? k : 0][VAR ? e : 0];
+              const T sx = aip * dn.v[e] + aim * up.v[e], sy = ajp * ea + ajm * w;
+              const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+              un = (f[k].v[e] + (ihx2 * sx + ihy2 * sy)) / ((sigma != T(0)) ? D0 + sigma : D0);
+            } else {
+              const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
+              un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
+            }
             const T res = one_m_omega * mid.v[e] + omega * un;
             const int gj = gj0 + e;
             if (gj >= 1 && gj < a.ny - 1) o.v[e] = res;
@@ -1465,7 +1647,16 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
         for (int e = 0; e < N; ++e) {
           const T w = (e == 0) ? left : mid.v[e - 1];
           const T ea = (e == N - 1) ? right : mid.v[e + 1];
-          const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + w) * ihy2) - mid.v[e] * D);
+          T au;
+          if (VAR) {
+            const T aip = av[VAR ? k + 1 : 0][VAR ? e : 0], aim = av[VAR ? k : 0][VAR ? e : 0];
+            const T ajp = ah[VAR ? k : 0][VAR ? e + 1 : 0], ajm = ah[VAR ? k : 0][VAR ? e : 0];
+            const T sx = aip * dn.v[e] + aim * up.v[e], sy = ajp * ea + ajm * w;
+            const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+            au = coeff * ((sx * ihx2 + sy * ihy2) - mid.v[e] * ((sigma != T(0)) ? D0 + sigma : D0));
+          } else {
+            au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + w) * ihy2) - mid.v[e] * D);
+          }
           const int gj = gj0 + e;
           if (gj >= 1 && gj < a.ny - 1) {
             o.v[e] = f[k].v[e] - au;

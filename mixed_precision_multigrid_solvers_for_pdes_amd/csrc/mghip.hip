@@ -84,6 +84,16 @@ inline Coef coefs(double hx, double hy, double sigma = 0.0) {
   return c;
 }
 
+// Upper bound of the per-workgroup partial sums any norm launch on an (nx, ny) field writes: the grid-stride
+// reductions use <= 2048 workgroups, the residual+norm kernel one per kTI-row tile, the fused up leg one per tile of
+// its own (shorter) tile height; fp64 tiles are the narrowest (64 columns).
+inline size_t max_partials(int nx, int ny) {
+  const long long tj = (ny + 63) / 64 + 1;
+  const int ti_min = std::min(mg::kTI, std::min(mg::kFusedTI, mg::kFusedTISmall));
+  const long long ti = (nx + ti_min - 1) / ti_min + 1;
+  return (size_t)std::max<long long>(2048, ti * tj);
+}
+
 inline int grid_for(long long work_items) {
   long long b = (work_items + mg::kBlock - 1) / mg::kBlock;
   return (int)std::max<long long>(1, std::min<long long>(b, 256 * 16));
@@ -246,6 +256,12 @@ void d_convert(int di, int dout, const void* in, void* out, int nx, int ny, int 
   else if (di == MG_F64 && dout == MG_F32) launch_convert<double, float>(in, out, nx, ny, ldi, ldo, st);
   else launch_convert<float, double>(in, out, nx, ny, ldi, ldo, st);
 }
+void d_zero_interior(int dt, void* u, int nx, int ny, int ld, hipStream_t st) {
+  if (nx < 3 || ny < 3) return;
+  const long long vecs = (long long)(nx - 2) * ((ny + (int)(16 / esize(dt)) - 1) / (int)(16 / esize(dt)));
+  if (dt == MG_F32) hipLaunchKernelGGL(mg::zero_interior_kernel<float>, dim3(grid_for(vecs)), dim3(mg::kBlock), 0, st, (float*)u, nx, ny, ld);
+  else hipLaunchKernelGGL(mg::zero_interior_kernel<double>, dim3(grid_for(vecs)), dim3(mg::kBlock), 0, st, (double*)u, nx, ny, ld);
+}
 void d_coarse(int dt, void* u, const void* rhs, int nx, int ny, int ld, double hx, double hy, double coeff,
               double omega, double tol, int maxit, int* sweeps_dev, hipStream_t st, bool zero_init = false,
               const void* a = nullptr, double sigma = 0.0) {
@@ -275,15 +291,15 @@ int d_var(int dt, const void* u, const void* a, const void* f, void* out, double
                       : launch_var<double, MODE>(u, a, f, out, partials, nx, ny, ld, hx, hy, omega, coeff, colour, poff, st, sigma);
 }
 template <typename TI, typename TO>
-void launch_inject(const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
+void launch_inject(const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, int stride, hipStream_t st) {
   hipLaunchKernelGGL((mg::inject_kernel<TI, TO>), dim3(grid_for((long long)nxc * nyc)), dim3(mg::kBlock), 0, st,
-                     (const TI*)fine, (TO*)coarse, ldf, nxc, nyc, ldc);
+                     (const TI*)fine, (TO*)coarse, ldf, nxc, nyc, ldc, stride);
 }
-void d_inject(int di, int dout, const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, hipStream_t st) {
-  if (di == MG_F32 && dout == MG_F32) launch_inject<float, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
-  else if (di == MG_F64 && dout == MG_F64) launch_inject<double, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
-  else if (di == MG_F64 && dout == MG_F32) launch_inject<double, float>(fine, coarse, ldf, nxc, nyc, ldc, st);
-  else launch_inject<float, double>(fine, coarse, ldf, nxc, nyc, ldc, st);
+void d_inject(int di, int dout, const void* fine, void* coarse, int ldf, int nxc, int nyc, int ldc, int stride, hipStream_t st) {
+  if (di == MG_F32 && dout == MG_F32) launch_inject<float, float>(fine, coarse, ldf, nxc, nyc, ldc, stride, st);
+  else if (di == MG_F64 && dout == MG_F64) launch_inject<double, double>(fine, coarse, ldf, nxc, nyc, ldc, stride, st);
+  else if (di == MG_F64 && dout == MG_F32) launch_inject<double, float>(fine, coarse, ldf, nxc, nyc, ldc, stride, st);
+  else launch_inject<float, double>(fine, coarse, ldf, nxc, nyc, ldc, stride, st);
 }
 
 // ------------------------------------------------------------------ fused legs ----------------
@@ -315,6 +331,7 @@ struct LegGeom {      // what every fused launch needs
   int ni_lo = -1, ni_hi = -1, nj_lo = -1, nj_hi = -1;     // norm window; -1: the interior
   int select = 0, in_i_lo = 0, in_i_hi = 0, in_j_lo = 0, in_j_hi = 0;   // tile selection (see mg::FusedArgs)
   double sigma = 0.0;                                                    // Helmholtz shift (see coefs)
+  const void* acoef = nullptr;                                           // variable coefficient: vertex values (dtype / pitch of u)
 };
 inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
   a.ci_off = g.ci_off; a.cj_off = g.cj_off; a.sides = g.sides;
@@ -324,7 +341,11 @@ inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
 
 // down leg: nsweep sweeps + residual + full-weighting restriction (interior coarse cells).  TX = coarse rhs dtype.
 // Tile height by level size: 32 rows where the launch is bandwidth-bound, 16 where it is latency-bound (<= ~1025^2).
-inline bool small_tiles(const LegGeom& g) { return (long long)g.nx * g.ny <= 1100LL * 1100LL; }
+// Variable-coefficient red-black GS keeps 6 halo cells and the face means of every owned cell in registers: with 32-row
+// tiles that is 176 VGPRs (one workgroup per CU); 16-row tiles stay at 100 (two).
+inline bool small_tiles(const LegGeom& g, int sm = mg::kSmJacobi) {
+  return (long long)g.nx * g.ny <= 1100LL * 1100LL || (g.acoef && sm == mg::kSmRbgs);
+}
 
 template <typename T, typename TX, int SM, int TI>
 void launch_down_ti(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
@@ -332,17 +353,21 @@ void launch_down_ti(const void* u, const void* rhs, void* out, void* rhs_c, cons
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
   apply_sub(a, g);
-  void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T);
-  if (zero_init) k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM, TI>
-                            : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 0, SM, TI>;
+  void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T, const T*, T);
+  if (g.acoef) {      // variable coefficient (one symbol for all levels: TAG 0)
+    k = zero_init ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 0, SM, TI, true>
+                  : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 0, SM, TI, true>;
+  } else if (zero_init) k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM, TI>
+                                   : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 0, SM, TI>;
   else k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 1, SM, TI>
                   : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr,
-                     (TX*)rhs_c, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+                     (TX*)rhs_c, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff,
+                     (const T*)g.acoef, (T)g.sigma);
 }
 template <typename T, typename TX, int SM>
 void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
-  if (small_tiles(g)) launch_down_ti<T, TX, SM, mg::kFusedTISmall>(u, rhs, out, rhs_c, g, zero_init, st);
+  if (small_tiles(g, SM)) launch_down_ti<T, TX, SM, mg::kFusedTISmall>(u, rhs, out, rhs_c, g, zero_init, st);
   else launch_down_ti<T, TX, SM, mg::kFusedTI>(u, rhs, out, rhs_c, g, zero_init, st);
 }
 
@@ -356,25 +381,29 @@ int launch_up_ti(const void* u, const void* rhs, void* out, const void* e_c, dou
     constexpr int HALO = 2 * mg::sweep_halo(SM) + 1;
     mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
     apply_sub(a, g);
-    auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM, TI>
+    auto k = g.acoef ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 0, SM, TI, true>
+           : g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM, TI>
                     : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 0, SM, TI>;
     hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
-                       (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+                       (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff,
+                       (const T*)g.acoef, (T)g.sigma);
     return a.ntiles;
   }
   constexpr int HALO = 2 * mg::sweep_halo(SM);
   mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
   apply_sub(a, g);
-  auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM, TI>
+  auto k = g.acoef ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 0, SM, TI, true>
+         : g.fine ? mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM, TI>
                   : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
-                     (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+                     (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff,
+                     (const T*)g.acoef, (T)g.sigma);
   return 0;
 }
 template <typename T, typename TX, typename TC, int SM>
 int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm,
               hipStream_t st) {
-  return small_tiles(g) ? launch_up_ti<T, TX, TC, SM, mg::kFusedTISmall>(u, rhs, out, e_c, partials, g, norm, st)
+  return small_tiles(g, SM) ? launch_up_ti<T, TX, TC, SM, mg::kFusedTISmall>(u, rhs, out, e_c, partials, g, norm, st)
                         : launch_up_ti<T, TX, TC, SM, mg::kFusedTI>(u, rhs, out, e_c, partials, g, norm, st);
 }
 
@@ -384,14 +413,16 @@ void launch_sweeps_ti(const void* u, const void* rhs, void* out, const LegGeom& 
   constexpr int HALO = 2 * mg::sweep_halo(SM);
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   const mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, 0, 0, 0, g.poff);
-  auto k = g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM, TI>
+  auto k = g.acoef ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 0, SM, TI, true>
+         : g.fine ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM, TI>
                   : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr,
-                     (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0);
+                     (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0,
+                     (const T*)g.acoef, (T)g.sigma);
 }
 template <typename T, int SM>
 void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
-  if (small_tiles(g)) launch_sweeps_ti<T, SM, mg::kFusedTISmall>(u, rhs, out, g, st);
+  if (small_tiles(g, SM)) launch_sweeps_ti<T, SM, mg::kFusedTISmall>(u, rhs, out, g, st);
   else launch_sweeps_ti<T, SM, mg::kFusedTI>(u, rhs, out, g, st);
 }
 
@@ -529,13 +560,13 @@ struct mg_handle {
     switch (cfg.precision) {
       case MG_PREC_SINGLE: return MG_F32;
       case MG_PREC_SINGLE_MANAGED: return MG_F32;
-      case MG_PREC_MIXED_LEVELS: return (l >= L() / 2) ? MG_F32 : MG_F64;
+      case MG_PREC_MIXED_LEVELS: return (l >= (cfg.mixed_split > 0 ? cfg.mixed_split : L() / 2)) ? MG_F32 : MG_F64;
       case MG_PREC_ADAPTIVE: return ph;
       default: return MG_F64;
     }
   }
   int level_dtype(int l) const { return level_dtype_in(l, phase); }
-  bool fused() const { return cfg.fused != 0 && !varcoef && (cfg.smoother == MG_JACOBI || cfg.smoother == MG_RBGS); }
+  bool fused() const { return cfg.fused != 0 && (cfg.smoother == MG_JACOBI || cfg.smoother == MG_RBGS); }
   bool needs(int l, int dt) const {
     if (cfg.precision == MG_PREC_ADAPTIVE) return (l == L() - 1) ? dt == grid_dtype : true;
     return level_dtype(l) == dt;
@@ -658,9 +689,10 @@ constexpr size_t kTailPoolLimit = 150 * 1024;
 
 size_t tail_pool_bytes(const mg_handle* h, int k, size_t esz, size_t esz_last) {
   size_t b = 0;
+  const size_t extra = h->varcoef ? 1 : 0;          // the coefficient field of every level rides along
   for (int l = k; l < h->L(); ++l) {
     const size_t cells = (size_t)h->lv[l].nx * h->lv[l].ny;
-    b += (l == h->L() - 1) ? 2 * cells * esz_last : 3 * cells * esz;
+    b += (l == h->L() - 1) ? (2 + extra) * cells * esz_last : (3 + extra) * cells * esz;
     b = (b + 15) / 16 * 16;
   }
   return b + (size_t)mg::kPipeCells * mg::kPipeSlots * esz_last;   // snapshot ring of the pipelined coarsest solve
@@ -679,14 +711,17 @@ void tail_schedule(const mg_handle* h, int k, int l, int zero_flag, std::vector<
 
 template <typename T, typename TCO, typename TC>
 int tail_set_attr(size_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&mg::coarse_tail_kernel<T, TCO, TC>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? MG_OK : MG_ERR_HIP;
+  return (hipFuncSetAttribute(reinterpret_cast<const void*>(&mg::coarse_tail_kernel<T, TCO, TC, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&mg::coarse_tail_kernel<T, TCO, TC, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) ? MG_OK : MG_ERR_HIP;
 }
 
 // Decide where the tail starts: the first level k >= 1 whose sub-hierarchy fits the LDS pool, has at most
 // kTailMaxLevels levels and (per-level MIXED policy) one dtype on levels k .. L-2.
 int plan_tail(mg_handle* h) {
   h->tail_start = -1;
+  if (h->d_tail_ops) { (void)hipFree(h->d_tail_ops); h->d_tail_ops = nullptr; }      // re-planned when the operator changes
   const int L = h->L();
   if (!h->fused() || L < 3 || h->cfg.pre > 8 || h->cfg.post > 8) return MG_OK;
   const size_t esz_last = esize(h->grid_dtype);
@@ -721,6 +756,9 @@ int launch_tail(mg_handle* h, bool zero_top) {
   a.ld_top = h->lv[k].ld[dt]; a.maxit = h->cfg.coarse_maxit;
   a.omega = h->cfg.omega; a.coeff = h->cfg.coeff; a.tol = h->cfg.coarse_tol;
   a.smoother = (h->cfg.smoother == MG_RBGS) ? mg::kSmRbgs : mg::kSmJacobi; a.colour_offset = h->cfg.colour_offset & 1;
+  a.sigma = h->sigma;
+  const bool var = h->varcoef;
+  const size_t extra = var ? 1 : 0;
   size_t off = 0;
   for (int l = k; l < L; ++l) {
     const Level& v = h->lv[l];
@@ -729,22 +767,26 @@ int launch_tail(mg_handle* h, bool zero_top) {
     t.nx = v.nx; t.ny = v.ny; t.off = (int)off;
     t.ihx2 = c.ihx2; t.ihy2 = c.ihy2; t.invD = c.invD; t.diag = c.diag; t.hx2 = v.hx * v.hx; t.hy2 = v.hy * v.hy;
     t.hxhy = v.hx * v.hy; t.use_div = c.pow2 ? 0 : 1; t.exact_recip = c.all_pow2 ? 1 : 0;
+    if (var) {     // hx^2, hy^2 powers of two are all the variable-coefficient solve needs to multiply by reciprocals
+      int e = 0;
+      t.exact_recip = (std::frexp(t.hx2, &e) == 0.5 && std::frexp(t.hy2, &e) == 0.5) ? 1 : 0;
+      const int dl = (l == L - 1) ? dco : dt;
+      a.a_lv[l - k] = v.a[dl]; a.a_ld[l - k] = v.ld[dl];
+    }
     const size_t cells = (size_t)v.nx * v.ny;
-    off += (l == L - 1) ? 2 * cells * esize(dco) : 3 * cells * esize(dt);
+    off += (l == L - 1) ? (2 + extra) * cells * esize(dco) : (3 + extra) * cells * esize(dt);
     off = (off + 15) / 16 * 16;
   }
   off += (size_t)mg::kPipeCells * mg::kPipeSlots * esize(dco);
   Level& top = h->lv[k];
   const dim3 grid(1), block(mg::kTailBlock);
-  if (dt == MG_F64)
-    hipLaunchKernelGGL((mg::coarse_tail_kernel<double, double, double>), grid, block, off, h->stream, (const double*)top.rhs[dt],
-                       (double*)top.u[dt], h->d_tail_ops, a, zero_top ? 1 : 0, h->d_int);
-  else if (dco == MG_F32)
-    hipLaunchKernelGGL((mg::coarse_tail_kernel<float, float, float>), grid, block, off, h->stream, (const float*)top.rhs[dt],
-                       (float*)top.u[dt], h->d_tail_ops, a, zero_top ? 1 : 0, h->d_int);
-  else
-    hipLaunchKernelGGL((mg::coarse_tail_kernel<float, double, double>), grid, block, off, h->stream, (const float*)top.rhs[dt],
-                       (float*)top.u[dt], h->d_tail_ops, a, zero_top ? 1 : 0, h->d_int);
+#define MG_TAIL_LAUNCH(T, TCO, TC, VAR)                                                                                     \
+  hipLaunchKernelGGL((mg::coarse_tail_kernel<T, TCO, TC, VAR>), grid, block, off, h->stream, (const T*)top.rhs[dt], (T*)top.u[dt], \
+                     h->d_tail_ops, a, zero_top ? 1 : 0, h->d_int)
+  if (dt == MG_F64) { if (var) MG_TAIL_LAUNCH(double, double, double, true); else MG_TAIL_LAUNCH(double, double, double, false); }
+  else if (dco == MG_F32) { if (var) MG_TAIL_LAUNCH(float, float, float, true); else MG_TAIL_LAUNCH(float, float, float, false); }
+  else { if (var) MG_TAIL_LAUNCH(float, double, double, true); else MG_TAIL_LAUNCH(float, double, double, false); }
+#undef MG_TAIL_LAUNCH
   return MG_OK;
 }
 
@@ -770,6 +812,7 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   const int sm = h->cfg.smoother;
   LegGeom g{f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, 0, h->cfg.colour_offset, fine};
   g.sigma = h->sigma;
+  if (h->varcoef) g.acoef = f.a[dt];
   if (part != kPartBack) {
     StageTimer tm(h, &f, 0);
     int extra = std::max(0, h->cfg.pre - 2);
@@ -839,9 +882,9 @@ int fmg_init(mg_handle* h, int ncyc) {
       (void)hipMemsetAsync(f.u[dt], 0, bytes, h->stream);
       if (f.t[dt]) (void)hipMemsetAsync(f.t[dt], 0, bytes, h->stream);
     } else {
-      // keep the Dirichlet ring: zero the interior by a residual-free trick -- u0 := ring only.  The ping-pong
-      // partner t already carries the ring (set_u_impl); copy it back, interior cells are overwritten below.
-      if (f.t[dt]) { HIPC(&h->err, hipMemcpyAsync(f.u[dt], f.t[dt], bytes, hipMemcpyDeviceToDevice, h->stream)); }
+      // keep the Dirichlet ring, zero the interior (whatever an initial guess or earlier cycles left there); the
+      // ping-pong partner t carries the same ring by invariant and is fully rewritten by the first leg
+      d_zero_interior(dt, f.u[dt], f.nx, f.ny, f.ld[dt], h->stream);
     }
     // interior cells: u = P e  (ADD = false writes every cell the interpolation defines, ring included: e ring is 0)
     if (l > 0) {
@@ -1146,10 +1189,8 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
     }
   }
   {
-    // fp64 tiles are the narrowest (32 x 64 cells): their count bounds every per-workgroup partial sum on level 0
-    const long long tiles = make_geom<double>(cfg->nx, cfg->ny, pitch_elems(MG_F64, cfg->ny), false).ntiles;
-    if ((rc = alloc_zero(&h->err, (void**)&h->partials, sizeof(double) * (size_t)std::max<long long>(2048, tiles), h->stream)) != MG_OK)
-      return bail(rc);
+    const size_t np = max_partials(cfg->nx, cfg->ny);
+    if ((rc = alloc_zero(&h->err, (void**)&h->partials, sizeof(double) * np, h->stream)) != MG_OK) return bail(rc);
   }
   if ((rc = alloc_zero(&h->err, (void**)&h->d_scalar, sizeof(double), h->stream)) != MG_OK) return bail(rc);
   if ((rc = alloc_zero(&h->err, (void**)&h->d_int, sizeof(int), h->stream)) != MG_OK) return bail(rc);
@@ -1260,30 +1301,30 @@ int mg_set_coefficient(mg_handle* h, const void* a_host, int host_dtype) {
   if (!h || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_coefficient: bad argument");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
   h->norm_partials = 0;
-  if (!a_host) { h->varcoef = false; return MG_OK; }       // back to the constant-coefficient operator
-  // the coefficient lives in every precision a level may compute in; coarse levels: injection (re-discretisation)
+  if (!a_host) {                                           // back to the constant-coefficient operator
+    const bool was = h->varcoef;
+    h->varcoef = false;
+    return was ? plan_tail(h) : MG_OK;
+  }
+  // The coefficient lives in every precision a level may compute in.  Level l takes every 2^l-th vertex value of the
+  // caller's array (injection = re-discretisation), cast ONCE from the caller's dtype to the level's: no level ever
+  // sees a value that went through a narrower precision on the way down.
+  Level& v0 = h->lv[0];
+  const int lds = pitch_elems(host_dtype, v0.ny);
+  HIPC(&h->err, hipMemcpy2DAsync(h->staging, (size_t)lds * esize(host_dtype), a_host, (size_t)v0.ny * esize(host_dtype),
+                                 (size_t)v0.ny * esize(host_dtype), v0.nx, hipMemcpyHostToDevice, h->stream));
   for (int l = 0; l < h->L(); ++l) {
     Level& v = h->lv[l];
     for (int dt = 0; dt < 2; ++dt) {
       if (!v.u[dt]) continue;
       if (!v.a[dt]) { const int rc = alloc_zero(&h->err, &v.a[dt], (size_t)v.nx * v.ld[dt] * esize(dt), h->stream); if (rc != MG_OK) return rc; }
-      if (l == 0) {
-        const int rc = upload(&h->err, v.a[dt], dt, v.ld[dt], a_host, host_dtype, v.nx, v.ny, h->staging, h->stream);
-        if (rc != MG_OK) return rc;
-      }
-    }
-    if (l > 0) {
-      Level& f = h->lv[l - 1];
-      for (int dt = 0; dt < 2; ++dt) {
-        if (!v.a[dt]) continue;
-        const int df = f.a[dt] ? dt : 1 - dt;          // inject from the same precision when the finer level has it
-        d_inject(df, dt, f.a[df], v.a[dt], f.ld[df], v.nx, v.ny, v.ld[dt], h->stream);
-      }
+      d_inject(host_dtype, dt, h->staging, v.a[dt], lds, v.nx, v.ny, v.ld[dt], 1 << l, h->stream);
     }
   }
   HIPC(&h->err, hipStreamSynchronize(h->stream));
+  const bool was = h->varcoef;
   h->varcoef = true;
-  return MG_OK;
+  return was ? MG_OK : plan_tail(h);                       // the LDS tail carries one more array per level
 }
 
 #if MG_EXP_TAIL_TRACE
@@ -1482,16 +1523,33 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
   Level& v = h->lv[level];
   const int dt = dtype;
   if (op != 6 && (!v.u[dt] || !v.rhs[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: level has no arrays of that dtype");
-  if (op == 0 && h->cfg.smoother != MG_JACOBI) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
-  if ((op == 0 || op >= 7) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no ping-pong buffer on this level");
+  if ((op == 0 || op == 10) && h->cfg.smoother != MG_JACOBI) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
+  if ((op == 0 || (op >= 7 && op <= 9)) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no ping-pong buffer on this level");
   if ((op == 2 || op == 4 || op == 5 || op == 7 || op == 8) && (level >= h->L() - 1 || !v.r[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no coarser level");
   h->norm_partials = 0;
+  // op 10: the single-sweep Jacobi kernel rotating over independent {u, rhs, out} sets whose total exceeds three
+  // times the 256 MiB Infinity Cache, so that no launch finds its operands on die: the HBM-proper smoother figure
+  std::vector<void*> hbm_sets;
+  struct FreeSets { std::vector<void*>& v; ~FreeSets() { for (void* p : v) (void)hipFree(p); } } free_sets{hbm_sets};
+  int nsets = 0, set_idx = 0;
+  if (op == 10) {
+    const size_t bytes = (size_t)v.nx * v.ld[dt] * esize(dt);
+    nsets = std::max<int>(3, (int)((768ull << 20) / (3 * bytes)) + 1);
+    for (int k = 0; k < 3 * nsets; ++k) {
+      void* p = nullptr;
+      HIPC(&h->err, hipMalloc(&p, bytes));
+      hbm_sets.push_back(p);
+      HIPC(&h->err, hipMemcpyAsync(p, (k % 3 == 1) ? v.rhs[dt] : v.u[dt], bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+  }
   hipEvent_t e0, e1;
   HIPC(&h->err, hipEventCreate(&e0));
   HIPC(&h->err, hipEventCreate(&e1));
   auto run = [&](int n) -> int {
     for (int k = 0; k < n; ++k) {
       switch (op) {
+        case 10: { void** b = hbm_sets.data() + 3 * (set_idx++ % nsets);
+                   d_jacobi(dt, b[0], b[1], b[2], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, level == 0); } break;
         case 0: d_jacobi(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, level == 0);
                 std::swap(v.u[dt], v.t[dt]); break;
         case 1: for (int c = 0; c < 2; ++c) d_rbgs_colour(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, c, h->cfg.colour_offset, h->stream, level == 0); break;
@@ -1567,9 +1625,7 @@ int mg_dev_residual(int dtype, int nx, int ny, int ld, double hx, double hy, dou
 
 int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes) {
   CHECK_DEV(bytes && nx >= 1 && ny >= 1, "mg_dev_scratch_bytes: bad argument");
-  // one fp64 partial per workgroup: <= 2048 for the grid-stride reductions, one per 32 x 512-byte tile for the up leg
-  const int64_t tiles = ((int64_t)(nx + mg::kFusedTISmall - 1) / mg::kFusedTISmall + 1) * ((int64_t)(ny + 63) / 64 + 1);
-  *bytes = (int64_t)sizeof(double) * std::max<int64_t>(2048, tiles);
+  *bytes = (int64_t)sizeof(double) * (int64_t)max_partials(nx, ny);
   return MG_OK;
 }
 
@@ -1609,13 +1665,23 @@ int mg_dev_prolong_add(int coarse_dtype, int fine_dtype, int compute_dtype, int 
 int mg_dev_down_leg(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
                     int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
                     const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream, int select, const int* inner_rect) {
+  return mg_dev_down_leg_var(smoother, dtype, coarse_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off, cj_off, hx, hy, omega, coeff, nsweep,
+                             zero_init, colour_offset, u, rhs, out, rhs_coarse, stream, select, inner_rect, nullptr);
+}
+
+int mg_dev_down_leg_var(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
+                        int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
+                        const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream, int select, const int* inner_rect,
+                        const void* acoef) {
   CHECK_DEV((smoother == MG_JACOBI || smoother == MG_RBGS) && valid_dtype(dtype) && valid_dtype(coarse_dtype), "mg_dev_down_leg: bad smoother / dtype");
+  CHECK_DEV(!acoef || aligned16(acoef), "mg_dev_down_leg: bad coefficient pointer");
   CHECK_DEV(nx >= 3 && ny >= 3 && nxc >= 3 && nyc >= 3 && ld_ok(dtype, ny, ld) && ldc >= nyc && nsweep >= 0 && nsweep <= 2, "mg_dev_down_leg: bad shape / pitch / sweep count");
   CHECK_DEV(rhs && out && rhs_coarse && (zero_init || u) && u != out && aligned16(rhs) && aligned16(out) && (!u || aligned16(u)), "mg_dev_down_leg: bad pointer");
   LegGeom g{nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, colour_offset, false};
   g.ci_off = ci_off; g.cj_off = cj_off;
   CHECK_DEV(select >= 0 && select <= 2 && (select == 0 || inner_rect), "mg_dev_down_leg: bad tile selection");
   if (select) { g.select = select; g.in_i_lo = inner_rect[0]; g.in_i_hi = inner_rect[1]; g.in_j_lo = inner_rect[2]; g.in_j_hi = inner_rect[3]; }
+  g.acoef = acoef;
   d_down(smoother, dtype, coarse_dtype, u ? u : rhs, rhs, out, rhs_coarse, g, zero_init != 0, (hipStream_t)stream);
   HIPC(nullptr, hipGetLastError());
   return MG_OK;
@@ -1625,12 +1691,23 @@ int mg_dev_up_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, 
                   int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
                   const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
                   int nj_hi, void* scratch, double* sumsq_dev, void* stream) {
+  return mg_dev_up_leg_var(smoother, dtype, coarse_dtype, compute_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off, cj_off, sides, hx, hy, omega,
+                           coeff, nsweep, colour_offset, u, rhs, out, e_coarse, norm, ni_lo, ni_hi, nj_lo, nj_hi, scratch, sumsq_dev,
+                           stream, nullptr);
+}
+
+int mg_dev_up_leg_var(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
+                      int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
+                      const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
+                      int nj_hi, void* scratch, double* sumsq_dev, void* stream, const void* acoef) {
   CHECK_DEV((smoother == MG_JACOBI || smoother == MG_RBGS) && valid_dtype(dtype) && valid_dtype(coarse_dtype) && valid_dtype(compute_dtype), "mg_dev_up_leg: bad smoother / dtype");
+  CHECK_DEV(!acoef || aligned16(acoef), "mg_dev_up_leg: bad coefficient pointer");
   CHECK_DEV(nx >= 3 && ny >= 3 && nxc >= 2 && nyc >= 2 && ld_ok(dtype, ny, ld) && ldc >= nyc && nsweep >= 0 && nsweep <= 2 && sides >= 0 && sides <= 15, "mg_dev_up_leg: bad shape / pitch / sweep count");
   CHECK_DEV(u && rhs && out && e_coarse && u != out && aligned16(u) && aligned16(rhs) && aligned16(out) && (!norm || (scratch && sumsq_dev)), "mg_dev_up_leg: bad pointer");
   LegGeom g{nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, colour_offset, false};
   g.ci_off = ci_off; g.cj_off = cj_off; g.sides = sides;
   if (norm) { g.ni_lo = ni_lo; g.ni_hi = ni_hi; g.nj_lo = nj_lo; g.nj_hi = nj_hi; }
+  g.acoef = acoef;
   const int n = d_up(smoother, dtype, coarse_dtype, compute_dtype, u, rhs, out, e_coarse, (double*)scratch, g, norm != 0, (hipStream_t)stream);
   if (n < 0) return fail(nullptr, MG_ERR_INVALID_VALUE, "mg_dev_up_leg: fp32 interpolation needs fp32 coarse and fine fields");
   if (norm) launch_reduce((double*)scratch, n, sumsq_dev, (hipStream_t)stream);

@@ -126,111 +126,142 @@ def distributed_levels(shapes, px, py, agglomerate_at, G=1):
 # kernels on torch tensors (device pointers into libmghip)
 # ------------------------------------------------------------------------------------------------
 class HipOps:
-    """mg_dev_* on CUDA tensors.  A field is a 2-D tensor (lnx, ld) whose first lny columns are the data."""
+    """mg_dev_* on CUDA tensors.  A field is a 2-D tensor (lnx, ld) whose first lny columns are the data; its precision
+    is the tensor's dtype (levels of one hierarchy may differ: per-level mixed precision)."""
 
-    def __init__(self, dtype, device, managed_single=False):
-        """managed_single (fp32 fields only): the reference's PrecisionManager('single') layout on a float64 Grid --
+    def __init__(self, dtype, device, managed_single=False, mixed=False):
+        """dtype: the default field precision (`alloc` without a dtype).
+        managed_single (fp32 fields only): the reference's PrecisionManager('single') layout on a float64 Grid --
         interpolation in fp64 and the coarsest level solved in fp64 (otherwise an fp32 coarsest solve can never
-        meet the 1e-12 tolerance and burns its 1000 sweeps on every visit, exactly like Grid(dtype=float32) does)."""
+        meet the 1e-12 tolerance and burns its 1000 sweeps on every visit, exactly like Grid(dtype=float32) does).
+        mixed: PrecisionManager('mixed') on a float64 Grid (core/precision.py:337-357): the caller allocates coarse
+        levels in fp32; interpolation runs in fp64 (the grid dtype)."""
         import torch
         self.torch = torch
         self.lib = _lib.load()
         self.np_dtype = np.dtype(dtype)
         self.dt = _lib.dtype_code(dtype)
         self.managed = bool(managed_single) and self.dt == _lib.MG_F32
-        self.comp_dt = _lib.MG_F64 if self.managed else self.dt
+        self.mixed = bool(mixed)
+        self.comp_dt = _lib.MG_F64 if (self.managed or self.mixed) else self.dt
         self.tdtype = torch.float32 if self.dt == _lib.MG_F32 else torch.float64
         self.device = device
-        nbytes = C.c_int64(0)
-        _lib.check(self.lib.mg_dev_scratch_bytes(16400, 16400, C.byref(nbytes)))      # enough for any block up to 16385^2
-        self.scratch = torch.zeros(nbytes.value // 8, dtype=torch.float64, device=device)
+        self.scratch = torch.zeros(2048, dtype=torch.float64, device=device)          # grown per field shape (_scratch_for)
         self.acc = torch.zeros(1, dtype=torch.float64, device=device)
         self._engine = None
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
 
-    def alloc(self, lnx, lny):
+    def _scratch_for(self, lnx, lny):
+        """Partial-sum scratch of at least mg_dev_scratch_bytes(lnx, lny) (the library writes one fp64 per workgroup)."""
+        nbytes = C.c_int64(0)
+        _lib.check(self.lib.mg_dev_scratch_bytes(int(lnx), int(lny), C.byref(nbytes)))
+        if self.scratch.numel() * 8 < nbytes.value:
+            self.scratch = self.torch.zeros(nbytes.value // 8, dtype=self.torch.float64, device=self.device)
+        return self._p(self.scratch)
+
+    def _code(self, t):
+        return _lib.MG_F32 if t.dtype == self.torch.float32 else _lib.MG_F64
+
+    def alloc(self, lnx, lny, dtype=None):
+        code = self.dt if dtype is None else _lib.dtype_code(dtype)
         ld = C.c_int(0)
-        _lib.check(self.lib.mg_pitch_elems(self.dt, lny, C.byref(ld)))
-        return self.torch.zeros((lnx, ld.value), dtype=self.tdtype, device=self.device)
+        _lib.check(self.lib.mg_pitch_elems(code, lny, C.byref(ld)))
+        return self.torch.zeros((lnx, ld.value), dtype=self.torch.float32 if code == _lib.MG_F32 else self.torch.float64,
+                                device=self.device)
 
     @staticmethod
     def _p(t):
         return C.c_void_p(t.data_ptr())
 
     def jacobi(self, u, rhs, out, lnx, lny, hx, hy, omega):
-        _lib.check(self.lib.mg_dev_jacobi(self.dt, lnx, lny, u.stride(0), hx, hy, omega, self._p(u), self._p(rhs),
+        _lib.check(self.lib.mg_dev_jacobi(self._code(u), lnx, lny, u.stride(0), hx, hy, omega, self._p(u), self._p(rhs),
                                           self._p(out), self._stream()))
 
     def rbgs_colour(self, u, rhs, lnx, lny, hx, hy, omega, colour, offset):
-        _lib.check(self.lib.mg_dev_rbgs_colour(self.dt, lnx, lny, u.stride(0), hx, hy, omega, colour, offset,
+        _lib.check(self.lib.mg_dev_rbgs_colour(self._code(u), lnx, lny, u.stride(0), hx, hy, omega, colour, offset,
                                                self._p(u), self._p(rhs), self._stream()))
 
     def residual(self, u, f, r, lnx, lny, hx, hy, coeff):
-        _lib.check(self.lib.mg_dev_residual(self.dt, lnx, lny, u.stride(0), hx, hy, coeff, self._p(u), self._p(f),
+        _lib.check(self.lib.mg_dev_residual(self._code(u), lnx, lny, u.stride(0), hx, hy, coeff, self._p(u), self._p(f),
                                             self._p(r), self._stream()))
 
     def sumsq(self, field, i_lo, i_hi, j_lo, j_hi):
         """fp64 sum of squares of the window as a 1-element device tensor."""
-        _lib.check(self.lib.mg_dev_sumsq(self.dt, field.stride(0), i_lo, i_hi, j_lo, j_hi, self._p(field),
-                                         self._p(self.scratch), self._p(self.acc), self._stream()))
+        _lib.check(self.lib.mg_dev_sumsq(self._code(field), field.stride(0), i_lo, i_hi, j_lo, j_hi, self._p(field),
+                                         self._scratch_for(i_hi, j_hi), self._p(self.acc), self._stream()))
         return self.acc.clone()
 
     def restrict(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides):
-        _lib.check(self.lib.mg_dev_restrict_fw(self.dt, self.dt, lnxf, lnyf, fine.stride(0), lnxc, lnyc,
+        _lib.check(self.lib.mg_dev_restrict_fw(self._code(fine), self._code(coarse), lnxf, lnyf, fine.stride(0), lnxc, lnyc,
                                                coarse.stride(0), sides, self._p(fine), self._p(coarse), self._stream()))
 
     def prolong_add(self, coarse, fine_u, lnxf, lnyf, lnxc, lnyc, sides):
-        _lib.check(self.lib.mg_dev_prolong_add(self.dt, self.dt, self.comp_dt, lnxf, lnyf, fine_u.stride(0), lnxc, lnyc,
-                                               coarse.stride(0), sides, self._p(coarse), self._p(fine_u), self._stream()))
+        _lib.check(self.lib.mg_dev_prolong_add(self._code(coarse), self._code(fine_u), self.comp_dt, lnxf, lnyf, fine_u.stride(0),
+                                               lnxc, lnyc, coarse.stride(0), sides, self._p(coarse), self._p(fine_u), self._stream()))
 
     # fused legs (mode "fused"): the single-GPU engine's kernels on the local array with its ghost zone
     supports_overlap = True
 
     def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff,
-                 select=0, inner=None):
-        """select: 0 all tiles; 1 only tiles that need nothing outside `inner` = (i_lo, i_hi, j_lo, j_hi); 2 the others."""
+                 select=0, inner=None, acoef=None):
+        """select: 0 all tiles; 1 only tiles that need nothing outside `inner` = (i_lo, i_hi, j_lo, j_hi); 2 the others.
+        acoef: vertex values of the diffusion coefficient on this array (None: constant-coefficient operator)."""
         rect = (C.c_int * 4)(*inner) if inner is not None else None
-        _lib.check(self.lib.mg_dev_down_leg(sm, self.dt, self.dt, lnx, lny, rhs.stride(0), lnxc, lnyc, rhs_c.stride(0), ci_off,
-                                            cj_off, hx, hy, omega, coeff, nsweep, int(zero_init), poff,
-                                            None if zero_init else self._p(u), self._p(rhs), self._p(out), self._p(rhs_c),
-                                            self._stream(), int(select), rect))
+        _lib.check(self.lib.mg_dev_down_leg_var(sm, self._code(rhs), self._code(rhs_c), lnx, lny, rhs.stride(0), lnxc, lnyc,
+                                                rhs_c.stride(0), ci_off, cj_off, hx, hy, omega, coeff, nsweep, int(zero_init), poff,
+                                                None if zero_init else self._p(u), self._p(rhs), self._p(out), self._p(rhs_c),
+                                                self._stream(), int(select), rect, None if acoef is None else self._p(acoef)))
 
     def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff,
-               window=None):
+               window=None, acoef=None):
         """out = sweeps(u + P e_c); with `window` = (i_lo, i_hi, j_lo, j_hi) also returns sum r^2 over it (device tensor)."""
         w = window or (0, 0, 0, 0)
-        _lib.check(self.lib.mg_dev_up_leg(sm, self.dt, self.dt, self.comp_dt, lnx, lny, u.stride(0), lnxc, lnyc, e_c.stride(0),
-                                          ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, self._p(u), self._p(rhs),
-                                          self._p(out), self._p(e_c), int(window is not None), w[0], w[1], w[2], w[3],
-                                          self._p(self.scratch), self._p(self.acc), self._stream()))
+        _lib.check(self.lib.mg_dev_up_leg_var(sm, self._code(u), self._code(e_c), self.comp_dt, lnx, lny, u.stride(0), lnxc, lnyc,
+                                              e_c.stride(0), ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, self._p(u),
+                                              self._p(rhs), self._p(out), self._p(e_c), int(window is not None), w[0], w[1], w[2],
+                                              w[3], self._scratch_for(lnx, lny), self._p(self.acc), self._stream(),
+                                              None if acoef is None else self._p(acoef)))
         return self.acc.clone() if window is not None else None
 
     def inject_ring(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides, ci_off, cj_off):
-        _lib.check(self.lib.mg_dev_inject_ring(self.dt, self.dt, lnxf, lnyf, fine.stride(0), lnxc, lnyc, coarse.stride(0), sides,
-                                               ci_off, cj_off, self._p(fine), self._p(coarse), self._stream()))
+        _lib.check(self.lib.mg_dev_inject_ring(self._code(fine), self._code(coarse), lnxf, lnyf, fine.stride(0), lnxc, lnyc,
+                                               coarse.stride(0), sides, ci_off, cj_off, self._p(fine), self._p(coarse), self._stream()))
 
     # replicated coarse hierarchy = the single-GPU engine on this GPU, queued on the same stream
     def coarse_setup(self, NX, NY, domain, cfg):
+        """cfg["mixed_split"] (per-level mixed only): first fp32 level counted from the agglomeration level; <= 0 means
+        every level of the replicated part but the coarsest is fp32."""
         from .engine import MultigridEngine
-        prec = (_lib.MG_PREC_SINGLE_MANAGED if self.managed else _lib.MG_PREC_SINGLE) if self.dt == _lib.MG_F32 else _lib.MG_PREC_DOUBLE
+        split = 0
+        if self.mixed:
+            split = int(cfg.get("mixed_split", 0))
+            prec = _lib.MG_PREC_MIXED_LEVELS if split > 0 else _lib.MG_PREC_SINGLE_MANAGED
+        elif self.dt == _lib.MG_F32:
+            prec = _lib.MG_PREC_SINGLE_MANAGED if self.managed else _lib.MG_PREC_SINGLE
+        else:
+            prec = _lib.MG_PREC_DOUBLE
         self._engine = MultigridEngine(NX, NY, domain, cfg["coeff"], cfg["levels"], cfg["cycle"], cfg["pre"], cfg["post"],
                                        cfg["smoother"], cfg["omega"], cfg["coarse_tol"], cfg["coarse_maxit"], prec,
-                                       device=self.device.index or 0)
+                                       device=self.device.index or 0, mixed_split=max(split, 0))
         _lib.check(self.lib.mg_set_stream(self._engine._h, self._stream(), 0))
+
+    def coarse_coefficient(self, a_host):
+        """vertex values of the diffusion coefficient on the agglomeration level (host array; None: constant)"""
+        self._engine.set_coefficient(a_host)
 
     def coarse_begin(self, rhs_global):
         e = self._engine
         _lib.check(self.lib.mg_set_stream(e._h, self._stream(), 0))
-        _lib.check(self.lib.mg_set_rhs_device(e._h, self._p(rhs_global), rhs_global.stride(0), self.dt))
+        _lib.check(self.lib.mg_set_rhs_device(e._h, self._p(rhs_global), rhs_global.stride(0), self._code(rhs_global)))
         _lib.check(self.lib.mg_zero_solution_device(e._h))
 
     def coarse_cycle(self):
         self._engine.cycle(1)
 
     def coarse_end(self, out_global):
-        _lib.check(self.lib.mg_get_solution_device(self._engine._h, self._p(out_global), out_global.stride(0), self.dt))
+        _lib.check(self.lib.mg_get_solution_device(self._engine._h, self._p(out_global), out_global.stride(0), self._code(out_global)))
 
     def close(self):
         if self._engine is not None:
@@ -268,6 +299,9 @@ class DistributedMultigrid:
     def __init__(self, NX, NY, px, py, ranks, ops, dist=None, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0,
                  max_levels=None, cycle="V", pre=2, post=2, smoother="jacobi", omega=0.8, coarse_tol=1e-12,
                  coarse_maxit=1000, agglomerate_at=1025, mode="auto", overlap=True):
+        """Precision: every level in ops.np_dtype, or -- with an `ops` built for per-level mixed precision (ops.mixed:
+        PrecisionManager('mixed'), core/precision.py:337-357) -- level l >= L // 2 in fp32 and the rest, like the
+        coarsest level, in fp64, decomposed and replicated levels alike."""
         from .facade import default_max_levels
         self.NX, self.NY, self.px, self.py = NX, NY, px, py
         self.ops, self.dist = ops, dist
@@ -289,6 +323,12 @@ class DistributedMultigrid:
         self.L = len(self.shapes)
         self.Ld = distributed_levels(self.shapes, px, py, agglomerate_at, self.G) if px * py > 1 else 0
         self.h = [((domain[1] - domain[0]) / (a - 1), (domain[3] - domain[2]) / (b - 1)) for a, b in self.shapes]
+        # precision of every level (see the docstring); the coarsest level is never converted (solvers/multigrid.py:270-272)
+        self.mixed = bool(getattr(ops, "mixed", False))
+        self.split = self.L // 2
+        self.ldt = [np.dtype(np.float32) if (self.mixed and l >= self.split and l != self.L - 1) else
+                    (np.dtype(np.float64) if self.mixed else np.dtype(ops.np_dtype)) for l in range(self.L)]
+        self.var = False                        # variable-coefficient operator (set_coefficient)
         self.ranks = list(ranks)
         self.doms = {}
         self.exchanges = 0                      # halo exchanges issued (statistics)
@@ -297,25 +337,28 @@ class DistributedMultigrid:
             d = _Dom()
             d.rank, d.rx, d.ry = r, rx, ry
             d.blk = [Block(a, b, px, py, rx, ry, self.G) for (a, b) in self.shapes[:self.Ld + 1]]
-            d.u, d.t, d.rhs, d.r = [], [], [], []
+            d.u, d.t, d.rhs, d.r, d.a = [], [], [], [], []
             for l in range(self.Ld):
                 b = d.blk[l]
-                d.u.append(ops.alloc(b.lnx, b.lny))
-                d.t.append(ops.alloc(b.lnx, b.lny) if (smoother == "jacobi" or self.mode == "fused") else None)
-                d.rhs.append(ops.alloc(b.lnx, b.lny))
-                d.r.append(ops.alloc(b.lnx, b.lny) if self.mode == "per_operator" else None)
+                d.u.append(ops.alloc(b.lnx, b.lny, self.ldt[l]))
+                d.t.append(ops.alloc(b.lnx, b.lny, self.ldt[l]) if (smoother == "jacobi" or self.mode == "fused") else None)
+                d.rhs.append(ops.alloc(b.lnx, b.lny, self.ldt[l]))
+                d.r.append(ops.alloc(b.lnx, b.lny, self.ldt[l]) if self.mode == "per_operator" else None)
+                d.a.append(None)
             # the agglomeration level: a local coarse buffer (restriction target / prolongation source)
             if self.Ld > 0:
                 b = d.blk[self.Ld]
-                d.rc = ops.alloc(b.lnx, b.lny)        # restricted rhs (its boundary ring is written once per rhs in fused mode)
-                d.ec = ops.alloc(b.lnx, b.lny)        # this rank's piece of the replicated correction
+                d.rc = ops.alloc(b.lnx, b.lny, self.ldt[self.Ld])   # restricted rhs (its boundary ring is written once per rhs in fused mode)
+                d.ec = ops.alloc(b.lnx, b.lny, self.ldt[self.Ld])   # this rank's piece of the replicated correction
+                d.zc = None                                          # zero correction for the level-1 block (variable-coefficient norm)
             d.ring_sumsq = None
             self.doms[r] = d
         NXa, NYa = self.shapes[self.Ld]
-        self.rhs_a = ops.alloc(NXa, NYa)
-        self.e_a = ops.alloc(NXa, NYa)
+        self.rhs_a = ops.alloc(NXa, NYa, self.ldt[self.Ld])
+        self.e_a = ops.alloc(NXa, NYa, self.ldt[self.Ld])
         ops.coarse_setup(NXa, NYa, domain, dict(coeff=coeff, levels=self.L - self.Ld, cycle=cycle, pre=pre, post=post,
-                                                smoother=self.smk, omega=omega, coarse_tol=coarse_tol, coarse_maxit=coarse_maxit))
+                                                smoother=self.smk, omega=omega, coarse_tol=coarse_tol, coarse_maxit=coarse_maxit,
+                                                mixed_split=self.split - self.Ld))
         # gather buffers: exclusive blocks padded to the largest block
         if self.Ld > 0:
             blocks = [Block(NXa, NYa, px, py, rx, ry, self.G) for rx in range(px) for ry in range(py)]
@@ -513,9 +556,10 @@ class DistributedMultigrid:
                 b, bc = d.blk[l], d.blk[l + 1]
                 ci, cj = b.coarse_offsets(bc)
                 target = d.rc if last else d.rhs[l + 1]
+                kw = {"acoef": d.a[l]} if self.var else {}
                 self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l], target, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, hx, hy,
                                   self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1,
-                                  select, inner_of(b) if select else None)
+                                  select, inner_of(b) if select else None, **kw)
 
         def inner_rect(b):      # cells whose values do not come out of an exchange: owned cells and physical boundary
             big = 1 << 30
@@ -553,8 +597,9 @@ class DistributedMultigrid:
             ci, cj = b.coarse_offsets(bc)
             e = d.ec if last else d.u[l + 1]
             win = (max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), max(b.j_lo, 1), min(b.j_hi, b.lny - 1)) if want_norm else None
+            kw = {"acoef": d.a[l]} if self.var else {}
             res = self.ops.up_leg(self.smk, d.u[l], d.rhs[l], d.t[l], e, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides, hx, hy,
-                                  self.omega, self.coeff, self.post, (b.gx0 + b.gy0) & 1, win)
+                                  self.omega, self.coeff, self.post, (b.gx0 + b.gy0) & 1, win, **kw)
             d.u[l], d.t[l] = d.t[l], d.u[l]
             if want_norm:
                 parts[r] = res + d.ring_sumsq
@@ -562,6 +607,8 @@ class DistributedMultigrid:
             self._last_norm_parts = parts
 
     def _cycle_per_operator(self, l):
+        if self.var:
+            raise NotImplementedError("the variable-coefficient operator runs on the fused legs (pre, post <= 2)")
         hx, hy = self.h[l]
         if self.pre > 0:
             self.smooth(l, self.pre)
@@ -591,15 +638,39 @@ class DistributedMultigrid:
             self.smooth(l, self.post)
 
     # ---- fields in / out -------------------------------------------------------------------------
+    def set_coefficient(self, a_at):
+        """Variable-coefficient operator A = coeff * div(a grad .) (BASELINE config 5; not in the reference).
+        a_at(ix, iy) -> 2-D array of the vertex values of a at GLOBAL FINE-grid indices (1-D integer arrays ix, iy).
+        Level l takes every 2^l-th fine vertex (injection, the single-GPU engine's rule), so every rank fills its blocks
+        of every level -- ghost zones included -- from the function alone: no exchange.  None: constant coefficients."""
+        torch = self.torch
+        if a_at is None:
+            self.var = False
+            self.ops.coarse_coefficient(None)
+            return
+        if self.mode != "fused":
+            raise NotImplementedError("the variable-coefficient operator runs on the fused legs (pre, post <= 2)")
+        for d in self.doms.values():
+            for l in range(self.Ld):
+                b = d.blk[l]
+                vals = np.asarray(a_at((b.gx0 + np.arange(b.lnx)) << l, (b.gy0 + np.arange(b.lny)) << l))
+                if d.a[l] is None:
+                    d.a[l] = self.ops.alloc(b.lnx, b.lny, self.ldt[l])
+                d.a[l][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(vals, dtype=self.ldt[l])).to(d.a[l].device)
+        NXa, NYa = self.shapes[self.Ld]
+        self.ops.coarse_coefficient(np.ascontiguousarray(a_at(np.arange(NXa) << self.Ld, np.arange(NYa) << self.Ld), dtype=np.float64))
+        self.var = True
+        self._last_norm_parts = None
+
     def set_problem(self, rhs_of_block, u0_of_block=None):
         """rhs_of_block(block) -> (lnx, lny) array of f on that block (ghost zone and boundary included)."""
         torch = self.torch
         for d in self.doms.values():
             b = d.blk[0]
-            d.rhs[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(rhs_of_block(b), dtype=self.ops.np_dtype)).to(d.rhs[0].device)
+            d.rhs[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(rhs_of_block(b), dtype=self.ldt[0])).to(d.rhs[0].device)
             d.u[0].zero_()
             if u0_of_block is not None:
-                d.u[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(u0_of_block(b), dtype=self.ops.np_dtype)).to(d.u[0].device)
+                d.u[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(u0_of_block(b), dtype=self.ldt[0])).to(d.u[0].device)
             if d.t[0] is not None:
                 d.t[0].copy_(d.u[0])
             if self.mode == "fused":
@@ -629,6 +700,20 @@ class DistributedMultigrid:
         if self.mode == "fused":
             self.exchange("u", 0)
         parts = {}
+        if self.var:
+            # no stand-alone variable-coefficient residual on device arrays: an up leg without sweeps on a zero correction
+            # (out = u + P 0 = u, then sum r^2 over the owned cells)
+            for r, d in self.doms.items():
+                b, bc = d.blk[0], d.blk[1]
+                ci, cj = b.coarse_offsets(bc)
+                if d.zc is None:
+                    d.zc = self.ops.alloc(bc.lnx, bc.lny, self.ldt[1])
+                win = (max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), max(b.j_lo, 1), min(b.j_hi, b.lny - 1))
+                res = self.ops.up_leg(self.smk, d.u[0], d.rhs[0], d.t[0], d.zc, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides, hx, hy,
+                                      self.omega, self.coeff, 0, (b.gx0 + b.gy0) & 1, win, acoef=d.a[0])
+                d.t[0].copy_(d.u[0])
+                parts[r] = res + d.ring_sumsq
+            return math.sqrt(hx * hy * self.allreduce_sum(parts))
         for r, d in self.doms.items():
             b = d.blk[0]
             tmp = d.r[0] if d.r[0] is not None else d.t[0]
@@ -713,15 +798,24 @@ def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1): BASELINE config 3's workload per GPU (4097^2, adaptive fp32 -> fp64, V(2,2) weighted
     Jacobi) on a px x py block decomposition -- weak scaling of the N = 1 bench line.  The precision policy is the
     engine's (core/precision.py:270-302 with the one-way promotion): start in double, drop to single while
-    ||r|| > 100 thr, promote for good once ||r|| < 10 thr; it switches between two solvers that share the decomposition."""
+    ||r|| > 100 thr, promote for good once ||r|| < 10 thr; it switches between two solvers that share the decomposition.
+
+    Test hook (tests/test_distributed_cpu.py): MG_DIST_BACKEND=gloo with MG_BENCH_OPS=module:Class runs the same driver
+    on CPU tensors with a stand-in kernel provider; without it the kernels are libmghip's and a GPU is required."""
+    import importlib
     import torch
     import torch.distributed as dist
-    assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if world != args.gpus:
+        raise RuntimeError(f"bench.py --gpus {args.gpus} under a launcher that started {world} ranks (WORLD_SIZE)")
     # rehearsal knobs (one-GPU box): MG_DIST_BACKEND=gloo MG_DIST_SAME_DEVICE=1 runs every rank on cuda:0 over gloo
     backend = os.environ.get("MG_DIST_BACKEND", "nccl")
+    ops_spec = os.environ.get("MG_BENCH_OPS") if backend == "gloo" else None
+    on_gpu = ops_spec is None
     if os.environ.get("MG_DIST_SAME_DEVICE") == "1":
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py --gpus N needs MI355X devices (no CPU fallback)"
+        torch.cuda.set_device(local_rank)
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -731,12 +825,19 @@ def bench_main(args, rank, local_rank, world):
     NX, NY = px * m + 1, py * m + 1
     # unit cells: the domain grows with the process grid so that hx = hy = 1/(n-1) as on one GPU
     domain = (0.0, float(px), 0.0, float(py))
-    dev = torch.device("cuda", local_rank)
     thr = 1e-6                                                    # BASELINE config 3: switch_threshold
+    if on_gpu:
+        dev = torch.device("cuda", local_rank)
+        providers = (("f32", HipOps(np.float32, dev, managed_single=True)), ("f64", HipOps(np.float64, dev)))
+    else:
+        modname, cls = ops_spec.split(":")
+        factory = getattr(importlib.import_module(modname), cls)
+        providers = (("f32", factory(np.float32)), ("f64", factory(np.float64)))
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     solvers = {}
-    for name, ops in (("f32", HipOps(np.float32, dev, managed_single=True)), ("f64", HipOps(np.float64, dev))):
+    for name, ops in providers:
         solvers[name] = DistributedMultigrid(NX, NY, px, py, [rank], ops, dist, domain=domain, smoother="jacobi", omega=0.8,
-                                             cycle="V", pre=2, post=2)
+                                             cycle="V", pre=2, post=2, agglomerate_at=getattr(args, "agglomerate_at", 1025))
 
     def reset():
         for sv in solvers.values():
@@ -759,22 +860,32 @@ def bench_main(args, rank, local_rank, world):
     for _ in range(W):
         rn = step(policy, rn)
     policy, rn = reset()
+    r0 = rn
     hist, phases = [], []
     for sv in solvers.values():
         sv.exchanges = 0
     dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(K):
         rn = step(policy, rn)
         hist.append(rn)
         phases.append(policy.phase)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if (on_gpu and backend == "nccl") else "cpu")
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    exchanges = sum(x.exchanges for x in solvers.values()) / max(1, K)
+    # iterations to tolerance / the plateau of the reference's absolute norm (untimed continuation of the same solve)
+    long_hist = list(hist)
+    for _ in range(max(0, 40 - K)):
+        rn = step(policy, rn)
+        long_hist.append(rn)
+    tail = sorted(long_hist[-5:])
+    floor = tail[len(tail) // 2]
+    first = lambda vals, t: next((k + 1 for k, v in enumerate(vals) if v < t), None)
     # roofline leg (rank 0): the dominant kernel of the timed region -- the level-0 up leg (prolongation + 2 sweeps +
     # norm) of the precision that ran most cycles -- on this rank's block, timed with events on its own stream
     dom = "f64" if phases.count("f64") >= phases.count("f32") else "f32"
@@ -789,20 +900,26 @@ def bench_main(args, rank, local_rank, world):
     def leg():
         sv.ops.up_leg(sv.smk, d0.u[0], d0.rhs[0], d0.t[0], e, b0.lnx, b0.lny, b1.lnx, b1.lny, ci, cj, b0.sides, hx0, hy0,
                       sv.omega, sv.coeff, sv.post, (b0.gx0 + b0.gy0) & 1, win)
-    reps = 20
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20 if on_gpu else 1
     leg()
-    ev0.record()
-    for _ in range(reps):
+    if on_gpu:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            leg()
+        ev1.record()
+        torch.cuda.synchronize()
+        ms_leg = ev0.elapsed_time(ev1) / reps
+    else:
+        t1 = time.perf_counter()
         leg()
-    ev1.record()
-    torch.cuda.synchronize()
-    ms_leg = ev0.elapsed_time(ev1) / reps
+        ms_leg = (time.perf_counter() - t1) * 1e3
     w = 8 if dom == "f64" else 4
-    alg, comp = 10.25 * w * b0.lnx * b0.lny, 3.25 * w * b0.lnx * b0.lny
+    moved, unfused = 3.25 * w * b0.lnx * b0.lny, 10.25 * w * b0.lnx * b0.lny
     if rank == 0:
         value = NX * NY * K / dt / 1e6
         s0 = solvers["f64"]
+        gbs = moved / (ms_leg * 1e-3) / 1e9
         print(json.dumps({
             "metric": "MDoF/s per V-cycle on 2D Poisson", "value": value, "unit": "MDoF/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -811,21 +928,26 @@ def bench_main(args, rank, local_rank, world):
                                    f"omega=0.8, {px}x{py} block decomposition ({args.n}^2 per GPU), RCCL halo exchange ({s0.mode} legs, "
                                    f"ghost width {s0.G}), {s0.L} levels ({s0.Ld} distributed, rest replicated after all-gather)",
                        "grid": [NX, NY], "levels": s0.L, "cycle": "V(2,2)", "smoother": "jacobi",
-                       "parallelism": f"dd{px}x{py}"},
+                       "parallelism": f"dd{px}x{py}", "backend": backend if on_gpu else f"{backend} (CPU rehearsal, {ops_spec})"},
             "cycles_fp32": phases.count("f32"), "cycles_fp64": phases.count("f64"),
-            "residual_first": hist[0], "residual_last": hist[-1],
+            "residual_initial": r0, "residual_first": hist[0], "residual_last": hist[-1],
+            "iterations": K, "iterations_to_1e-10_absolute": first(long_hist, 1e-10),
+            "iterations_to_1e-10_relative": first([v / r0 for v in long_hist], 1e-10),
+            "iterations_to_1e-9_absolute": first(long_hist, 1e-9),
+            "residual_floor": floor, "iterations_to_floor": first(long_hist, 2.0 * floor),
             "roofline": {"bound": "hbm", "kernel": f"fused_jacobi_kernel up_leg {dom} on the local {b0.lnx}x{b0.lny} block (rank 0, level 0)",
-                         "achieved": alg / (ms_leg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg / (ms_leg * 1e-3) / 1e9 / 8000.0, "traffic": None, "launch_ms": ms_leg,
-                         "algorithmic_bytes_per_launch": alg, "compulsory_bytes_per_launch": comp,
-                         "compulsory_gbs": comp / (ms_leg * 1e-3) / 1e9, "compulsory_frac": comp / (ms_leg * 1e-3) / 1e9 / 8000.0,
-                         "note": "achieved = algorithmic bytes (SURVEY 8d per-operator accounting) / launch time; a fused leg "
-                                 "moves the fields once (compulsory_*)"},
-            "exchanges_per_cycle": sum(x.exchanges for x in solvers.values()) / max(1, K),
+                         "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "launch_ms": ms_leg,
+                         "bytes_per_launch": moved, "unfused_equivalent_bytes": unfused,
+                         "unfused_equivalent_gbs": unfused / (ms_leg * 1e-3) / 1e9,
+                         "note": "achieved = bytes the launch must move (3.25 words per cell of the local block, ghost zone "
+                                 "included) / launch time; unfused_equivalent_* prices the same work as one launch per operator "
+                                 "(SURVEY 8d)"},
+            "exchanges_per_cycle": exchanges,
             "note": "distributed levels: communication-avoiding fused legs (two launches and about one halo exchange per "
                     "level and cycle, orchestrated from Python over torch.distributed P2P); the replicated coarse "
                     "hierarchy runs on the fused single-GPU engine; same precision policy as the N = 1 line",
-        }))
+        }), flush=True)
     for x in solvers.values():
         x.close()
     dist.destroy_process_group()
+    return 0

@@ -12,7 +12,8 @@ class MultigridEngine:
     def __init__(self, nx, ny, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0, max_levels=4, cycle="V", pre=2, post=2,
                  smoother=_lib.MG_JACOBI, omega=0.8, coarse_tol=1e-12, coarse_maxit=1000,
                  precision=_lib.MG_PREC_DOUBLE, switch_threshold=1e-6, memory_threshold_gb=4.0,
-                 adaptive_reference_rule=False, device=0, profile=False, colour_offset=0, fused=True, tail=True, speculate=True, fmg_cycles=0):
+                 adaptive_reference_rule=False, device=0, profile=False, colour_offset=0, fused=True, tail=True, speculate=True, fmg_cycles=0,
+                 mixed_split=0):
         lib = _lib.load()
         if isinstance(cycle, str):
             if cycle not in _lib.CYCLES:
@@ -22,7 +23,8 @@ class MultigridEngine:
                             float(coeff), int(max_levels), int(cycle), int(pre), int(post), int(smoother),
                             float(omega), float(coarse_tol), int(coarse_maxit), int(precision),
                             float(switch_threshold), float(memory_threshold_gb), int(bool(adaptive_reference_rule)),
-                            int(device), int(bool(profile)), int(colour_offset), int(bool(fused)), int(bool(tail)), int(fmg_cycles), int(bool(speculate)))
+                            int(device), int(bool(profile)), int(colour_offset), int(bool(fused)), int(bool(tail)), int(fmg_cycles), int(bool(speculate)),
+                            int(mixed_split))
         self.cfg = cfg
         self._h = C.c_void_p(None)
         _lib.check(lib.mg_create(C.byref(cfg), C.byref(self._h)))
@@ -153,7 +155,7 @@ class MultigridEngine:
 
     def time_op(self, op, level=0, dtype=np.float64, reps=20):
         ops = {"jacobi": 0, "rbgs": 1, "residual": 2, "residual_norm": 3, "restrict": 4, "prolong": 5, "cycle": 6,
-               "down_leg": 7, "up_leg": 8, "sweeps2": 9}
+               "down_leg": 7, "up_leg": 8, "sweeps2": 9, "jacobi_hbm": 10}
         out = C.c_double(0.0)
         self._check(self._lib.mg_time_op(self._h, ops[op] if isinstance(op, str) else int(op), int(level),
                                          _lib.dtype_code(dtype), int(reps), C.byref(out)))

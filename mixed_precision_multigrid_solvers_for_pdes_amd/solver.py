@@ -62,10 +62,15 @@ class MultigridSolver(BaseSolver):
     # -- setup (solvers/multigrid.py:91-182) -------------------------------------------------
     def setup(self, fine_grid, operator, restriction_op, prolongation_op, smoother=None, coarse_solver=None):
         if smoother is None:
-            # the reference's default is a *lexicographic* Gauss-Seidel smoother, which is sequential;
-            # its parallel twin keeps the reference's own red-black sweep order (smoothers.py:175-207).
+            # the reference's default (solvers/multigrid.py:112-117): a *lexicographic* Gauss-Seidel smoother.  It is
+            # sequential by nature -- one workgroup sweeping anti-diagonals (MG_LEXGS) -- so the drop-in default is
+            # parity, not speed: pass GaussSeidelSmoother(red_black=True) or a Jacobi smoother for the fast legs.
             smoother = GaussSeidelSmoother(max_iterations=max(self.pre_smooth_iterations, self.post_smooth_iterations),
-                                           tolerance=self.tolerance * 0.1, red_black=True)
+                                           tolerance=self.tolerance * 0.1)
+            if fine_grid.nx * fine_grid.ny > 513 * 513:
+                warnings.warn("MultigridSolver.setup(smoother=None) keeps the reference's default lexicographic "
+                              "Gauss-Seidel smoother, which runs on one workgroup; pass "
+                              "GaussSeidelSmoother(red_black=True) or a Jacobi smoother for the bandwidth-bound legs")
         if not isinstance(smoother, IterativeSolver) or smoother.kind is None:
             raise TypeError("smoother must be a JacobiSmoother / GaussSeidelSmoother (or subclass)")
         if coarse_solver is not None and not (isinstance(coarse_solver, GaussSeidelSmoother) and not coarse_solver.red_black):

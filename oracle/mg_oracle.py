@@ -458,41 +458,58 @@ def var_coarse_residual(u, f, a, hx, hy, coeff, shift=0.0):
 
 
 class VarMGOracle(MGOracle):
-    """MGOracle with A = coeff * div(a grad .): same cycle, variable-coefficient smoother / residual / coarsest solve."""
+    """MGOracle with A = coeff * div(a grad .): same cycle, variable-coefficient smoother / residual / coarsest solve.
+    The coefficient of level l is every 2^l-th vertex value of the caller's array (re-discretisation), cast once to the
+    precision the level computes in (csrc/mghip.hip mg_set_coefficient does the same)."""
 
     def __init__(self, a, *args, **kw):
         super().__init__(a.shape[0], a.shape[1], *args, **kw)
-        self.a = [np.asarray(a, dtype=self.dtype)]
-        for _ in self.shapes[1:]:
-            self.a.append(self.a[-1][::2, ::2].copy())
+        self.a_src = np.asarray(a)
+        self._a_cache = {}
+        self.a = [self.a_of(l, self.dtype) for l in range(len(self.shapes))]
+
+    def a_of(self, level, dtype):
+        key = (level, np.dtype(dtype).str)
+        if key not in self._a_cache:
+            self._a_cache[key] = np.ascontiguousarray(self.a_src[::2**level, ::2**level]).astype(dtype)
+        return self._a_cache[key]
 
     def _smooth(self, u, level, nu):
         hx, hy = self.h[level]
+        a = self.a_of(level, u.dtype)
         if self.smoother == "jacobi":
-            return var_jacobi(u, self.rhs[level], self.a[level], hx, hy, self.omega, nu, self.shift)
-        return var_rbgs(u, self.rhs[level], self.a[level], hx, hy, self.omega, nu, self.shift)
+            return var_jacobi(u, self.rhs[level], a, hx, hy, self.omega, nu, self.shift)
+        return var_rbgs(u, self.rhs[level], a, hx, hy, self.omega, nu, self.shift)
 
     def residual_norm(self, u, rhs, level=0):
         hx, hy = self.h[level]
-        return float(l2_norm(var_residual(u, rhs, self.a[level], hx, hy, self.coeff, self.shift), hx, hy))
+        return float(l2_norm(var_residual(u, rhs, self.a_of(level, u.dtype), hx, hy, self.coeff, self.shift), hx, hy))
 
     def cycle_once(self, u, level=0, pm=None):
         L = len(self.shapes)
         hx, hy = self.h[level]
-        if level == L - 1:
+        if level == L - 1:                         # never converted: the grid dtype (solvers/multigrid.py:270-272)
             u = u.copy()
+            a = self.a_of(level, u.dtype)
+            sweeps = self.cmaxit
             for it in range(1, self.cmaxit + 1):
-                var_lexgs_sweep(u, self.rhs[level], self.a[level], hx, hy, self.shift)
-                if l2_norm(var_coarse_residual(u, self.rhs[level], self.a[level], hx, hy, self.coeff, self.shift), hx, hy) < self.ctol:
+                var_lexgs_sweep(u, self.rhs[level], a, hx, hy, self.shift)
+                if l2_norm(var_coarse_residual(u, self.rhs[level], a, hx, hy, self.coeff, self.shift), hx, hy) < self.ctol:
+                    sweeps = it
                     break
+            self.coarse_sweeps.append(sweeps)
             return u
+        if pm is not None:                         # multigrid.py:275-285
+            p = pm.for_level(level, L)
+            u = pm.convert(u, p)
+            self.rhs[level] = pm.convert(self.rhs[level], p)
         u = self._smooth(u, level, self.pre)
-        r = var_residual(u, self.rhs[level], self.a[level], hx, hy, self.coeff, self.shift)
+        r = var_residual(u, self.rhs[level], self.a_of(level, u.dtype), hx, hy, self.coeff, self.shift)
         self.rhs[level + 1] = restrict_fw(r, self.dtype).copy()
         e = np.zeros_like(self.rhs[level + 1])
         reps = 1 if self.cycle == "V" else 2 if self.cycle == "W" else max(1, 2 ** (L - level - 2))
         for _ in range(reps):
-            e = self.cycle_once(e, level + 1)
+            e = self.cycle_once(e, level + 1, pm)
         u += prolong_bilinear(e, self.dtype)
         return self._smooth(u, level, self.post)
 

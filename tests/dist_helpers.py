@@ -10,14 +10,20 @@ SIDE_ILO, SIDE_IHI, SIDE_JLO, SIDE_JHI = 1, 2, 4, 8
 
 
 class NumpyOps:
-    def __init__(self, dtype=np.float64):
+    def __init__(self, dtype=np.float64, mixed=False):
+        """mixed: per-level mixed precision on a float64 Grid (the driver allocates coarse levels in fp32): interpolation
+        in fp64, like HipOps(mixed=True)."""
         self.torch = torch
         self.np_dtype = np.dtype(dtype)
         self.tdtype = torch.float32 if self.np_dtype == np.float32 else torch.float64
+        self.mixed = bool(mixed)
+        self.comp_dtype = np.dtype(np.float64) if self.mixed else self.np_dtype
         self._mg = None
+        self._coef = None
 
-    def alloc(self, lnx, lny):
-        return torch.zeros((lnx, lny + 3), dtype=self.tdtype)      # a few pad columns, like the pitched device layout
+    def alloc(self, lnx, lny, dtype=None):
+        td = self.tdtype if dtype is None else (torch.float32 if np.dtype(dtype) == np.float32 else torch.float64)
+        return torch.zeros((lnx, lny + 3), dtype=td)      # a few pad columns, like the pitched device layout
 
     @staticmethod
     def _v(t, lnx, lny):
@@ -63,7 +69,7 @@ class NumpyOps:
                         c[a, b] = f[2 * a, 2 * b]
 
     def prolong_add(self, coarse, fine_u, lnxf, lnyf, lnxc, lnyc, sides):
-        e, u = self._v(coarse, lnxc, lnyc), self._v(fine_u, lnxf, lnyf)
+        e, u = self._v(coarse, lnxc, lnyc).astype(self.comp_dtype), self._v(fine_u, lnxf, lnyf)
         i = np.arange(lnxf)[:, None]; j = np.arange(lnyf)[None, :]
         ic, io, jc, jo = i >> 1, i & 1, j >> 1, j & 1
         valid = (ic + io < lnxc) & (jc + jo < lnyc)
@@ -76,7 +82,8 @@ class NumpyOps:
             P = np.where((io == 1) & (jo == 0) & (j == lnyf - 1), 0.0, P)
         if sides & SIDE_IHI:
             P = np.where((io == 0) & (jo == 1) & (i == lnxf - 1), 0.0, P)
-        u[valid] = (u + P.astype(u.dtype))[valid]
+        wide = np.result_type(u.dtype, P.dtype)
+        u[valid] = (u.astype(wide) + P.astype(wide)).astype(u.dtype)[valid]
 
     # ---- fused legs with sub-domain semantics (every edge of the local array is treated as fixed) ----------------
     def _prolong_field(self, e, lnxf, lnyf, lnxc, lnyc, ci_off, cj_off, sides, dtype):
@@ -85,6 +92,7 @@ class NumpyOps:
         valid = (ic >= 0) & (jc >= 0) & (ic + io < lnxc) & (jc + jo < lnyc)
         icc, jcc = np.clip(ic, 0, lnxc - 1), np.clip(jc, 0, lnyc - 1)
         ic1, jc1 = np.clip(ic + 1, 0, lnxc - 1), np.clip(jc + 1, 0, lnyc - 1)
+        e = e.astype(self.comp_dtype)          # interpolation arithmetic in the grid's dtype (operators/transfer.py:207)
         e00, e01, e10, e11 = e[icc, jcc], e[icc, jc1], e[ic1, jcc], e[ic1, jc1]
         P = np.where((io == 0) & (jo == 0), e00,
             np.where((io == 1) & (jo == 0), 0.5 * (e00 + e10),
@@ -93,10 +101,24 @@ class NumpyOps:
             P = np.where((io == 1) & (jo == 0) & (j == lnyf - 1), 0.0, P)
         if sides & SIDE_IHI:
             P = np.where((io == 0) & (jo == 1) & (i == lnxf - 1), 0.0, P)
-        return P.astype(dtype), valid
+        return P, valid            # in comp_dtype; the caller adds in the wider of (u, P) and rounds to u's dtype
 
-    def _sweeps(self, sm, v, f, hx, hy, omega, nsweep, poff):
-        """nsweep sweeps of the local array: weighted Jacobi (sm = 0) or red-black GS with the global colouring (sm = 1)."""
+    def _sweeps(self, sm, v, f, hx, hy, omega, nsweep, poff, a=None):
+        """nsweep sweeps of the local array: weighted Jacobi (sm = 0) or red-black GS with the global colouring (sm = 1);
+        a: vertex values of the diffusion coefficient (variable-coefficient operator)."""
+        if a is not None:
+            if sm == 0:
+                return O.var_jacobi(v, f, a, hx, hy, omega, nsweep)
+            v = v.copy()
+            lnx, lny = v.shape
+            i = np.arange(1, lnx - 1)[:, None]; j = np.arange(1, lny - 1)[None, :]
+            for _ in range(nsweep):
+                for colour in (0, 1):
+                    m = ((i + j + poff) % 2) == colour
+                    upd = O._var_update(v, f, a, hx, hy, omega)
+                    inner = v[1:-1, 1:-1]
+                    inner[m] = upd[m]
+            return v
         if sm == 0:
             return O.jacobi(v, f, hx, hy, omega, nsweep, "vectorized")
         v = v.copy()
@@ -113,13 +135,14 @@ class NumpyOps:
         return v
 
     def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff,
-                 select=0, inner=None):
+                 select=0, inner=None, acoef=None):
         assert select == 0          # no streams on the CPU: the driver never splits the launch here
         f = self._v(rhs, lnx, lny)
+        a = None if acoef is None else self._v(acoef, lnx, lny)
         v = np.zeros_like(f) if zero_init else self._v(u, lnx, lny).copy()
-        v = self._sweeps(sm, v, f, hx, hy, omega, nsweep, poff)
+        v = self._sweeps(sm, v, f, hx, hy, omega, nsweep, poff, a)
         self._v(out, lnx, lny)[1:, :] = v[1:, :]                    # the kernel never writes row 0
-        r = O.residual(v, f, hx, hy, coeff)
+        r = O.residual(v, f, hx, hy, coeff) if a is None else O.var_residual(v, f, a, hx, hy, coeff)
         c = self._v(rhs_c, lnxc, lnyc)
         ic = np.arange(1, lnxc - 1); jc = np.arange(1, lnyc - 1)
         fi = 2 * (ic - ci_off); fj = 2 * (jc - cj_off)
@@ -129,16 +152,19 @@ class NumpyOps:
         edges = ((r[I - 1, J] + r[I + 1, J]) + r[I, J - 1]) + r[I, J + 1]
         c[np.ix_(ic[oki], jc[okj])] = (1.0 / 16.0 * corners + 1.0 / 8.0 * edges) + 1.0 / 4.0 * r[I, J]
 
-    def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, window=None):
+    def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, window=None,
+               acoef=None):
         f = self._v(rhs, lnx, lny)
+        a = None if acoef is None else self._v(acoef, lnx, lny)
         v = self._v(u, lnx, lny).copy()
         P, valid = self._prolong_field(self._v(e_c, lnxc, lnyc), lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, v.dtype)
-        v[valid] = (v + P)[valid]
-        v = self._sweeps(sm, v, f, hx, hy, omega, nsweep, poff)
+        wide = np.result_type(v.dtype, P.dtype)
+        v[valid] = (v.astype(wide) + P.astype(wide)).astype(v.dtype)[valid]
+        v = self._sweeps(sm, v, f, hx, hy, omega, nsweep, poff, a)
         self._v(out, lnx, lny)[1:, :] = v[1:, :]
         if window is None:
             return None
-        r = O.residual(v, f, hx, hy, coeff)
+        r = O.residual(v, f, hx, hy, coeff) if a is None else O.var_residual(v, f, a, hx, hy, coeff)
         i_lo, i_hi, j_lo, j_hi = window
         w = r[max(i_lo, 1):min(i_hi, lnx - 1), max(j_lo, 1):min(j_hi, lny - 1)].astype(np.float64)
         return torch.tensor([float(np.sum(w * w))], dtype=torch.float64)
@@ -157,17 +183,37 @@ class NumpyOps:
 
     # replicated coarse hierarchy: the oracle's single-domain cycle
     def coarse_setup(self, NX, NY, domain, cfg):
-        kind = {0: "jacobi", 1: "rbgs"}[cfg["smoother"]]
-        self._mg = O.MGOracle(NX, NY, domain, self.np_dtype, cfg["coeff"], cfg["levels"], cfg["cycle"], cfg["pre"],
-                              cfg["post"], kind, cfg["omega"], "vectorized", cfg["coarse_tol"], cfg["coarse_maxit"])
+        self._kind = {0: "jacobi", 1: "rbgs"}[cfg["smoother"]]
+        self._cfg, self._domain = dict(cfg), domain
         self._shape = (NX, NY)
+        self._pm = None
+        if self.mixed:      # the replicated levels keep the GLOBAL split: level >= mixed_split (counted from here) is fp32
+            split = int(cfg.get("mixed_split", 0))
+
+            class _Split:
+                def for_level(self_, level, nlevels):
+                    return "float32" if level >= split else "float64"
+                convert = staticmethod(lambda arr, p: arr if arr.dtype == np.dtype(p) else arr.astype(p))
+            self._pm = _Split()
+        self._build_mg(None)
+
+    def _build_mg(self, a):
+        cfg = self._cfg
+        NX, NY = self._shape
+        dt = np.float64 if self.mixed else self.np_dtype
+        args = (self._domain, dt, cfg["coeff"], cfg["levels"], cfg["cycle"], cfg["pre"], cfg["post"], self._kind, cfg["omega"],
+                "vectorized", cfg["coarse_tol"], cfg["coarse_maxit"])
+        self._mg = O.MGOracle(NX, NY, *args) if a is None else O.VarMGOracle(a, *args)
+
+    def coarse_coefficient(self, a_host):
+        self._build_mg(None if a_host is None else np.asarray(a_host, dtype=np.float64))
 
     def coarse_begin(self, rhs_global):
         self._mg.rhs[0] = self._v(rhs_global, *self._shape).copy()
-        self._e = np.zeros(self._shape, dtype=self.np_dtype)
+        self._e = np.zeros(self._shape, dtype=self._mg.rhs[0].dtype)
 
     def coarse_cycle(self):
-        self._e = self._mg.cycle_once(self._e, 0)
+        self._e = self._mg.cycle_once(self._e, 0, self._pm)
 
     def coarse_end(self, out_global):
         self._v(out_global, *self._shape)[...] = self._e

@@ -206,6 +206,21 @@ def gen_large():
     print(f"  1025^2: {info['iterations']} cycles, {dt / info['iterations']:.2f} s/cycle (reference CPU path, 1 core)")
 
 
+def gen_large4097():
+    """The bench size itself (BASELINE config 3's grid): two V(2,2) Jacobi-0.8 cycles of the reference's own CPU solver
+    at 4097^2 fp64, 11 levels -- its seconds per cycle is the `reference_cpu_captured` figure bench.py quotes
+    (gpu/gpu_benchmark.py:246-248 metric), the history and a strided sample pin the GPU engine at full size."""
+    u, info, dt = run_solve(4097, 11, "V", "vjacobi08", maxit=2, tol=0.0)
+    save("large_4097.npz",
+         hist=np.array(info["residual_history"]),
+         u_sample=u[::128, ::128].copy(),
+         u_linf=np.array(np.max(np.abs(u))),
+         u_l2=np.array(np.sqrt(np.sum(u * u))),
+         seconds_per_cycle=np.array(dt / info["iterations"]),
+         cores=np.array(1))
+    print(f"  4097^2: {info['iterations']} cycles, {dt / info['iterations']:.2f} s/cycle (reference CPU path, 1 core)")
+
+
 from heat_inputs import heat_cases, heat_config                          # noqa: E402  (tests/golden/heat_inputs.py)
 
 
@@ -250,3 +265,5 @@ if __name__ == "__main__":
         gen_solves()
     if "large" in which:
         gen_large()
+    if "large4097" in which:
+        gen_large4097()

@@ -245,3 +245,33 @@ def test_adaptive_policy_host_port():
     r = D.AdaptivePolicy(1e-6)
     assert r.before_cycle(5e-5) == "f64"                        # small first residual: stay in double
     assert not D.stagnating([1.0, 0.1, 0.01, 0.001, 0.0001]) and D.stagnating([1.0, 1.0, 1.0, 1.0, 1.0])
+
+
+def test_bench_py_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (how the driver's scaling run may start it): the parent spawns the
+    two ranks, waits and relays rank 0's ONE JSON line.  Rehearsed on CPU over gloo with the NumPy stand-in kernels
+    (MG_BENCH_OPS test hook); the decomposition, policy, timing and reporting code is the one the GPU run executes."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MG_DIST_BACKEND="gloo", MG_BENCH_OPS="dist_helpers:NumpyOps", OMP_NUM_THREADS="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, env.get("PYTHONPATH", "")]))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--grid-n", "65", "--agglomerate-at", "17"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "iterations", "residual_floor", "iterations_to_floor"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dd2x1"
+    assert d["config"]["grid"] == [129, 65]
+    assert abs(d["value"] - 129 * 65 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) < 1e-6 * d["value"]
+    assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["unit"] == "GB/s"
+    # the solve itself: starts in double, drops to single on the large first residual (AdaptivePolicy), contracts
+    assert d["cycles_fp32"] >= 1 and d["residual_first"] < 0.2 * d["residual_initial"]
+    # a rank that fails must fail the launcher
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--grid-n", "64", "--agglomerate-at", "17"], env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0

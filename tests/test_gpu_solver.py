@@ -23,7 +23,9 @@ def _smoother(name):
             "jacobi23": lambda: mg.JacobiSmoother(),
             "rbgs": lambda: mg.GaussSeidelSmoother(red_black=True),
             "rbgs15": lambda: mg.GaussSeidelSmoother(red_black=True, relaxation_parameter=1.15),
-            "lexgs": lambda: mg.GaussSeidelSmoother()}[name]()
+            # the lexgs goldens were produced by the reference's DEFAULT smoother (setup(smoother=None),
+            # solvers/multigrid.py:112-117): go through the same default here
+            "lexgs": lambda: None}[name]()
 
 
 def _run(g, key):
@@ -257,6 +259,44 @@ def test_fmg_initial_guess_equals_oracle(n, cyc, kind, omega, ncyc, fused):
     _, plain = mg.MixedPrecisionMultigrid("double", tolerance=1e-8, smoother="jacobi" if kind == "jacobi" else "gauss_seidel").solve(prob)
     _, fmg = mg.MixedPrecisionMultigrid("double", tolerance=1e-8, smoother="jacobi" if kind == "jacobi" else "gauss_seidel", use_fmg=True).solve(prob)
     assert fmg["converged"] and fmg["iterations"] < plain["iterations"]
+
+
+@pytest.mark.parametrize("sm,fused", [(0, True), (1, True), (1, False), (2, False)])
+def test_fmg_ignores_call_history(sm, fused):
+    """mg_fmg builds its guess from the rhs and the Dirichlet ring alone: the interior of an earlier iterate (an initial
+    guess, or whatever previous cycles left in the ping-pong buffers) must not leak into it."""
+    n = 129
+    rng = np.random.default_rng(5)
+    rhs = O.sine_rhs(n, n)
+    ring = np.zeros((n, n)); ring[0, :] = rng.standard_normal(n); ring[:, -1] = rng.standard_normal(n)
+    junk = ring + np.pad(rng.standard_normal((n - 2, n - 2)), 1)
+    eng = mg.MultigridEngine(n, n, max_levels=6, smoother=sm, omega=0.8 if sm == 0 else 1.0, fused=fused)
+    eng.set_rhs(rhs)
+    eng.set_solution(ring); eng.fmg(1)
+    u_clean = eng.get_solution()
+    eng.set_solution(junk); eng.cycle(3); eng.fmg(1)
+    u_after = eng.get_solution()
+    eng.close()
+    np.testing.assert_array_equal(u_after[0, :], ring[0, :]); np.testing.assert_array_equal(u_after[:, -1], ring[:, -1])
+    np.testing.assert_array_equal(u_after, u_clean)
+
+
+def test_default_smoother_is_the_references_lexicographic_gs(golden_solves):
+    """setup(smoother=None) == setup(smoother=GaussSeidelSmoother()) (solvers/multigrid.py:112-117), not red-black."""
+    grid = mg.Grid(33, 33)
+    op = mg.LaplacianOperator(coefficient=-1.0)
+    rhs = O.sine_rhs(33, 33)
+    out = []
+    for sm in (None, mg.GaussSeidelSmoother(), mg.GaussSeidelSmoother(red_black=True)):
+        s = mg.MultigridSolver(max_levels=4, max_iterations=30, tolerance=1e-10)
+        s.setup(grid, op, mg.RestrictionOperator("full_weighting"), mg.ProlongationOperator("bilinear"), smoother=sm)
+        assert s.smoother.red_black == (sm is not None and sm.red_black)
+        out.append(s.solve(grid, op, rhs))
+        s.cleanup()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][1]["residual_history"] == out[1][1]["residual_history"]
+    assert out[0][1]["residual_history"] != out[2][1]["residual_history"]
+    np.testing.assert_allclose(out[0][1]["residual_history"], golden_solves["n33_L4_V_lexgs_float64__hist"], rtol=1e-9, atol=5e-14)
 
 
 def test_config5_size_16385_mixed_w_rbgs_single_gpu():
