@@ -1,0 +1,253 @@
+// Register-blocked fused legs (weighted Jacobi / red-black GS, constant coefficients) for the bandwidth-bound levels.
+//
+// Same legs as fused_jacobi_kernel (mg_kernels.hpp) -- down: sweeps -> residual -> full-weighting restriction; up:
+// u += P e -> sweeps [-> sum r^2]; plain: sweeps -- and the same arithmetic per cell (bit-identical results), but the
+// iterate never lives in LDS:
+//
+//   * a workgroup of W waves owns a region of RI = W * RPT rows x 1 KB; every WAVE owns RPT consecutive rows of it, a
+//     lane the same 16-byte column slot of each: u and rhs of the lane's RPT x N cells stay in registers for the whole
+//     leg, loaded up front (2 RPT 16-byte loads per lane in flight: 16 KB per wave, 128 KB per workgroup -- the
+//     "whole tile at once" access shape that streams at the rate of a copy, profiles/README.md);
+//   * vertical neighbours: rows k -+ 1 of the lane's own strip; across strips the top / bottom row of every wave goes
+//     through a small LDS exchange buffer once per stage (2 writes + 2 reads of 16 bytes per lane and stage instead of
+//     RPT writes + RPT + 2 reads + 2 RPT scalar reads of the LDS-tiled kernel);
+//   * lateral neighbours: lane -+ 1 by DPP wave_shr:1 / wave_shl:1 -- a wave spans the whole region width, so the only
+//     lanes without a neighbour are region-edge lanes, whose cells are halo (stale by construction);
+//   * halo: HALO rows above / below, kRbHL lanes (4 x 16 bytes) left / right: the tile is 56 lanes = 896 bytes = seven
+//     128-byte lines wide, so every tile row starts on a line boundary;
+//   * full weighting in registers too (rows k -+ 1 of the residual strip, DPP for the west column): no LDS r-tile.
+//
+// LDS: the exchange buffer (2 x W x 2 KB) and, for the up leg, the coarse patch under the region.
+#pragma once
+
+#include "mg_kernels.hpp"
+
+namespace mg {
+
+constexpr int kRbHL = 4;                 // halo LANES per side (16 bytes each): tile rows start on 128-byte lines
+
+template <typename T, int HALO, int W, int RPT> struct RbShape {
+  static constexpr int N = VecW<T>::N;
+  static constexpr int RI = W * RPT;                 // region rows
+  static constexpr int RJ = 64 * N;                  // region cols (one wave = one region row segment of 1 KB)
+  static constexpr int TI = RI - 2 * HALO;           // tile rows
+  static constexpr int TJ = (64 - 2 * kRbHL) * N;    // tile cols
+  static_assert(TI > 0 && TI % 2 == 0, "tile height must be even (coarse rows sit on every other tile row)");
+  static_assert(kRbHL * N >= HALO, "lateral halo too narrow");
+};
+
+template <typename T> __device__ __forceinline__ T dpp_from_lower_lane(T x);     // lane l receives lane l-1's value (0 for lane 0)
+template <typename T> __device__ __forceinline__ T dpp_from_upper_lane(T x);     // lane l receives lane l+1's value (0 for lane 63)
+template <> __device__ __forceinline__ float dpp_from_lower_lane<float>(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));      // wave_shr:1
+}
+template <> __device__ __forceinline__ float dpp_from_upper_lane<float>(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));      // wave_shl:1
+}
+template <> __device__ __forceinline__ double dpp_from_lower_lane<double>(double x) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true));
+}
+template <> __device__ __forceinline__ double dpp_from_upper_lane<double>(double x) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true));
+}
+
+// Exchange of the strips' edge rows: every wave publishes its first and last row, then reads the last row of the wave
+// above and the first row of the wave below (zeros beyond the region).  `xb`: W x 2 x 64 packs.
+template <typename T, int W>
+__device__ __forceinline__ void rb_exchange(Pack<T>* __restrict__ xb, int w, int lane, const Pack<T>& top, const Pack<T>& bottom,
+                                            Pack<T>& above, Pack<T>& below) {
+  xb[(w * 2 + 0) * 64 + lane] = top;
+  xb[(w * 2 + 1) * 64 + lane] = bottom;
+  __syncthreads();
+  above = (w > 0) ? xb[((w - 1) * 2 + 1) * 64 + lane] : zero_pack<T>();
+  below = (w < W - 1) ? xb[((w + 1) * 2 + 0) * 64 + lane] : zero_pack<T>();
+}
+
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int W, int RPT>
+__global__ __launch_bounds__(W * 64) void rb_leg_kernel(
+    const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
+    const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
+    TX* __restrict__ rhs_coarse,          // POST == kPostRestrict: coarse rhs (dtype TX)
+    double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 per block
+    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
+  using S = RbShape<T, HALO, W, RPT>;
+  constexpr int N = S::N;
+  constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
+  constexpr size_t kXBytes = (size_t)2 * W * 2 * 64 * sizeof(Pack<T>);
+  constexpr size_t kPatchBytes = PROLONG ? (size_t)PH * PW * sizeof(TX) : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kXBytes + kPatchBytes];
+  __shared__ double red[W];
+  Pack<T>* const xbuf = reinterpret_cast<Pack<T>*>(lds);
+  TX* const patch = reinterpret_cast<TX*>(lds + kXBytes);
+
+  const int L = xcd_remap(blockIdx.x, a.ntiles);
+  const int ti = L / a.tiles_j, tj = L - ti * a.tiles_j;
+  const int i0 = 1 + ti * S::TI, j0 = tj * S::TJ;
+  const int ri0 = i0 - HALO, rj0 = j0 - kRbHL * N;                // global coords of region cell (0, 0)
+  if (a.select != 0) {
+    const bool inner = ri0 >= a.in_i_lo && ri0 + S::RI <= a.in_i_hi && rj0 >= a.in_j_lo && rj0 + S::RJ <= a.in_j_hi;
+    if ((a.select == 1) != inner) {
+      if (POST == kPostNorm && threadIdx.x == 0) partials[blockIdx.x] = 0.0;
+      return;
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int gj0 = rj0 + lane * N;
+  const int r_base = w * RPT;
+  const bool col_in = gj0 >= 0 && gj0 < a.nyv;
+
+  // ---- load: the whole strip at once -----------------------------------------------------------------------------
+  if (PROLONG) {
+    const int pic0 = (ri0 >> 1) + a.ci_off, pjc0 = (rj0 >> 1) + a.cj_off;       // coarse cell of patch entry (0, 0)
+    for (int idx = threadIdx.x; idx < PH * PW; idx += W * 64) {
+      const int pr = idx / PW, pc = idx - pr * PW;
+      const int ic = pic0 + pr, jc = pjc0 + pc;
+      patch[idx] = (ic >= 0 && ic < a.nxc && jc >= 0 && jc < a.nyc) ? e_coarse[(size_t)ic * a.ldc + jc] : TX(0);
+    }
+  }
+  Pack<T> F[RPT], U[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int gi = ri0 + r_base + k;
+    F[k] = zero_pack<T>();
+    U[k] = zero_pack<T>();
+    if (gi >= 0 && gi < a.nx && col_in) {
+      F[k] = ldg(rhs + (size_t)gi * a.ld + gj0);
+      if (!ZERO_INIT) U[k] = ldg(u + (size_t)gi * a.ld + gj0);
+    }
+  }
+  if (PROLONG) {
+    __syncthreads();
+    using TS = typename std::conditional<(sizeof(TC) > sizeof(T)), TC, T>::type;
+    const int pic0 = (ri0 >> 1) + a.ci_off, pjc0 = (rj0 >> 1) + a.cj_off;
+    const TX* pe = patch - ((ptrdiff_t)pic0 * PW + pjc0);                       // the patch addressed like the coarse array
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int gi = ri0 + r_base + k;
+      if (gi >= 0 && gi < a.nx && col_in) {
+        TC val[N];
+        bool ok[N];
+        prolong_vec<TX, TC, N>(pe, PW, a.nxc, a.nyc, gi, gj0, a.nx, a.ny, a.sides, val, ok, a.ci_off, a.cj_off);
+#pragma unroll
+        for (int e = 0; e < N; ++e)
+          if (ok[e]) U[k].v[e] = (T)((TS)U[k].v[e] + (TS)val[e]);
+      }
+    }
+  }
+
+  // ---- sweeps ------------------------------------------------------------------------------------------------------
+  int stage = 0;
+  const int npass = (SM == kSmRbgs) ? 2 * a.nsweep : a.nsweep;
+  for (int s = 0; s < npass; ++s, ++stage) {
+    Pack<T> above, below;
+    rb_exchange<T, W>(xbuf + (size_t)(stage & 1) * W * 2 * 64, w, lane, U[0], U[RPT - 1], above, below);
+    const int colour = s & 1;
+    Pack<T> prev = above;                         // the (old) row above the one being updated
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int r = r_base + k, gi = ri0 + r;
+      const Pack<T> mid = U[k];
+      const Pack<T> dn = (k < RPT - 1) ? U[k + 1] : below;
+      const T left = dpp_from_lower_lane<T>(mid.v[N - 1]);       // every lane active here
+      const T right = dpp_from_upper_lane<T>(mid.v[0]);
+      Pack<T> o = mid;
+      if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
+          const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
+          const T nb = ihx2 * (dn.v[e] + prev.v[e]) + ihy2 * (ea + wv);
+          const T un = a.use_div ? (F[k].v[e] + nb) / D : (F[k].v[e] + nb) * invD;
+          const T res = one_m_omega * mid.v[e] + omega * un;
+          const int gj = gj0 + e;
+          const bool mine = (SM != kSmRbgs) || (((gi + gj + a.colour_offset) & 1) == colour);
+          if (gj >= 1 && gj < a.ny - 1 && mine) o.v[e] = res;
+        }
+      }
+      U[k] = o;
+      prev = (SM == kSmRbgs) ? o : mid;           // red-black GS is in place: the neighbours it reads are not of this colour
+    }
+  }
+
+  // ---- write the tile of u' ------------------------------------------------------------------------------------------
+  const bool lane_in_tile = lane >= kRbHL && lane < 64 - kRbHL;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int r = r_base + k, gi = ri0 + r;
+    if (r >= HALO && r < HALO + S::TI && lane_in_tile && gi < a.nx && gj0 < a.nyv) stg(out + (size_t)gi * a.ld + gj0, U[k]);
+  }
+  if (POST == kPostNone) return;
+
+  // ---- residual of the strip (r = f on boundary cells, as f is 0 outside the grid so is r) ------------------------------
+  Pack<T> R[RPT];
+  double acc = 0.0;
+  {
+    Pack<T> above, below;
+    rb_exchange<T, W>(xbuf + (size_t)(stage & 1) * W * 2 * 64, w, lane, U[0], U[RPT - 1], above, below);
+    ++stage;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int r = r_base + k, gi = ri0 + r;
+      const Pack<T> up = (k > 0) ? U[k - 1] : above;
+      const Pack<T> mid = U[k];
+      const Pack<T> dn = (k < RPT - 1) ? U[k + 1] : below;
+      const T left = dpp_from_lower_lane<T>(mid.v[N - 1]);
+      const T right = dpp_from_upper_lane<T>(mid.v[0]);
+      Pack<T> o = F[k];
+      const bool in_tile = r >= HALO && r < HALO + S::TI && lane_in_tile;
+      const bool wanted = (POST == kPostRestrict) || in_tile;        // the norm only needs r on the tile itself
+      if (wanted && r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
+          const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
+          const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + wv) * ihy2) - mid.v[e] * D);
+          const int gj = gj0 + e;
+          if (gj >= 1 && gj < a.ny - 1) {
+            o.v[e] = F[k].v[e] - au;
+            if (POST == kPostNorm && in_tile && gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi)
+              acc += (double)o.v[e] * (double)o.v[e];
+          }
+        }
+      }
+      R[k] = o;
+    }
+  }
+  if (POST == kPostNorm) {
+    const double t = block_reduce_sum<W>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    return;
+  }
+
+  // ---- full weighting of the interior coarse cells that sit on this tile (operators/transfer.py:100-124) -------------
+  {
+    Pack<T> above, below;
+    rb_exchange<T, W>(xbuf + (size_t)(stage & 1) * W * 2 * 64, w, lane, R[0], R[RPT - 1], above, below);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int r = r_base + k, fi = ri0 + r;
+      const Pack<T> up = (k > 0) ? R[k - 1] : above;
+      const Pack<T> mid = R[k];
+      const Pack<T> dn = (k < RPT - 1) ? R[k + 1] : below;
+      // west neighbours of the lane's first cell, from the lane below (all lanes active)
+      const T nw0 = dpp_from_lower_lane<T>(up.v[N - 1]), w0 = dpp_from_lower_lane<T>(mid.v[N - 1]), sw0 = dpp_from_lower_lane<T>(dn.v[N - 1]);
+      if ((fi & 1) || r < HALO || r >= HALO + S::TI || !lane_in_tile) continue;       // coarse rows sit on even fine rows
+      const int ic = (fi >> 1) + a.ci_off;
+      if (ic < 1 || ic > a.nxc - 2 || fi < 1 || fi > a.nx - 2) continue;
+#pragma unroll
+      for (int e = 0; e < N; e += 2) {                                                 // gj0 is even: e even = coarse column
+        const int fj = gj0 + e, jc = (fj >> 1) + a.cj_off;
+        if (jc < 1 || jc > a.nyc - 2 || fj < 1 || fj > a.ny - 2) continue;
+        const T NWv = (e == 0) ? nw0 : up.v[e > 0 ? e - 1 : 0], Wv = (e == 0) ? w0 : mid.v[e > 0 ? e - 1 : 0],
+                SWv = (e == 0) ? sw0 : dn.v[e > 0 ? e - 1 : 0];
+        const T corners = ((NWv + up.v[e + 1]) + SWv) + dn.v[e + 1];
+        const T edges = ((up.v[e] + dn.v[e]) + Wv) + mid.v[e + 1];
+        rhs_coarse[(size_t)ic * a.ldc + jc] = (TX)((T(1.0 / 16.0) * corners + T(1.0 / 8.0) * edges) + T(1.0 / 4.0) * mid.v[e]);
+      }
+    }
+  }
+}
+
+}  // namespace mg

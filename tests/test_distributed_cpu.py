@@ -275,3 +275,118 @@ def test_bench_py_gpus_2_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                           "--grid-n", "64", "--agglomerate-at", "17"], env=env, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
+
+
+# ---------------------------------------------------------------- variable coefficient, per-level mixed precision ----
+def _a_at(NX, NY):
+    """a(x, y) = 1 + 0.5 sin(2 pi x) cos(2 pi y) at global fine-grid indices."""
+    x, y = np.linspace(0.0, 1.0, NX), np.linspace(0.0, 1.0, NY)
+    return lambda ix, iy: 1.0 + 0.5 * np.sin(2 * np.pi * x[ix])[:, None] * np.cos(2 * np.pi * y[iy])[None, :]
+
+
+def _var_oracle(NX, NY, levels, cyc, kind, omega, ncycles, mixed):
+    a = _a_at(NX, NY)(np.arange(NX), np.arange(NY))
+    mgo = O.VarMGOracle(a, (0.0, 1.0, 0.0, 1.0), np.float64, -1.0, levels, cyc, 2, 2, kind, omega, "vectorized", coarse_maxit=40)
+    pm = O.OraclePrecision("mixed") if mixed else None
+    rhs = _rhs(NX, NY, (0.0, 1.0, 0.0, 1.0))
+    mgo.rhs[0] = rhs.copy()
+    u = _u0(NX, NY)
+    hist = []
+    for _ in range(ncycles):
+        u = mgo.cycle_once(u, 0, pm)
+        mgo.rhs[0] = rhs.copy()                 # the mixed cycle converts rhs[0] in place on entry; same values, fp64 here
+        hist.append(mgo.residual_norm(u.astype(np.float64), rhs, 0))
+    return u, hist
+
+
+@pytest.mark.parametrize("px,py,NX,NY,agg,cyc,kind,omega,mixed", [
+    (2, 1, 129, 65, 33, "V", "jacobi", 0.8, False), (2, 2, 129, 129, 33, "W", "jacobi", 0.8, False),
+    (2, 2, 257, 257, 65, "W", "rbgs", 1.0, False), (2, 1, 257, 129, 65, "V", "rbgs", 1.15, False),
+    # per-level mixed: 257^2 has 7 levels, split at level 3 (33^2); agg = 17 keeps 257..33 decomposed: an fp32 DISTRIBUTED level
+    (2, 2, 257, 257, 17, "V", "jacobi", 0.8, True), (2, 2, 257, 257, 65, "W", "jacobi", 0.8, True), (4, 2, 513, 257, 17, "V", "jacobi", 0.8, True)])
+def test_variable_coefficient_and_mixed_levels_virtual_ranks(px, py, NX, NY, agg, cyc, kind, omega, mixed):
+    """BASELINE config 5's ingredients in the decomposed driver: -div(a grad u) with a coefficient field per block
+    (ghost zone filled from the function, no exchange) and per-level mixed precision on decomposed AND replicated
+    levels.  Owned cells equal the single-domain oracle (VarMGOracle, our own restatement: parity unpinned) bit for bit."""
+    levels = len(D.hierarchy_shapes(NX, NY, 99))
+    u_ref, h_ref = _var_oracle(NX, NY, levels, cyc, kind, omega, 2, mixed)
+    rhs, u0 = _rhs(NX, NY, (0.0, 1.0, 0.0, 1.0)), _u0(NX, NY)
+    s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), H.NumpyOps(np.float64, mixed=mixed), None, max_levels=levels, cycle=cyc,
+                               smoother=kind, omega=omega, agglomerate_at=agg, coarse_maxit=40, mode="fused")
+    s.set_coefficient(_a_at(NX, NY))
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+    if mixed:
+        assert s.ldt[0] == np.float64 and s.ldt[s.split] == np.float32 and s.ldt[-1] == np.float64
+        if agg == 17:
+            assert s.Ld > s.split                        # an fp32 level is decomposed
+    n0 = s.residual_norm()                               # the stand-alone norm path of the variable-coefficient operator
+    mg0 = O.VarMGOracle(_a_at(NX, NY)(np.arange(NX), np.arange(NY)), max_levels=levels)
+    np.testing.assert_allclose(n0, mg0.residual_norm(u0, rhs, 0), rtol=1e-13)
+    hist = []
+    for _ in range(2):
+        s.cycle(0)
+        hist.append(s.residual_norm())
+    np.testing.assert_array_equal(H.assemble(s, NX, NY), u_ref)
+    np.testing.assert_allclose(hist, h_ref, rtol=1e-13)
+
+
+def test_mixed_levels_constant_coefficient_virtual_ranks():
+    """Per-level mixed precision alone (PrecisionManager('mixed')): decomposed == MGOracle with the per-level policy."""
+    NX = NY = 257
+    levels = len(D.hierarchy_shapes(NX, NY, 99))
+    mgo = O.MGOracle(NX, NY, (0.0, 1.0, 0.0, 1.0), np.float64, -1.0, levels, "V", 2, 2, "rbgs", 1.0, "vectorized", coarse_maxit=40)
+    pm = O.OraclePrecision("mixed")
+    rhs, u0 = _rhs(NX, NY, (0.0, 1.0, 0.0, 1.0)), _u0(NX, NY)
+    u = u0.copy()
+    for _ in range(2):
+        mgo.rhs[0] = rhs.copy()
+        u = mgo.cycle_once(u, 0, pm)
+    s = D.DistributedMultigrid(NX, NY, 2, 2, range(4), H.NumpyOps(np.float64, mixed=True), None, max_levels=levels, cycle="V",
+                               smoother="rbgs", omega=1.0, agglomerate_at=17, coarse_maxit=40, mode="fused")
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+    for _ in range(2):
+        s.cycle(0)
+    np.testing.assert_array_equal(H.assemble(s, NX, NY), u)
+
+
+def _var_worker(rank, world, port, px, py, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    NX = NY = 257
+    levels = len(D.hierarchy_shapes(NX, NY, 99))
+    rhs, u0 = _rhs(NX, NY, (0.0, 1.0, 0.0, 1.0)), _u0(NX, NY)
+    s = D.DistributedMultigrid(NX, NY, px, py, [rank], H.NumpyOps(np.float64, mixed=True), dist, max_levels=levels, cycle="W",
+                               smoother="rbgs", omega=1.0, agglomerate_at=33, coarse_maxit=40, mode="fused")
+    s.set_coefficient(_a_at(NX, NY))
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+    hist = []
+    for _ in range(2):
+        s.cycle(0)
+        hist.append(s.residual_norm())
+    b, u = s.local_solution(rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (b.gx0, b.gy0, b.i_lo, b.i_hi, b.j_lo, b.j_hi, u))
+    if rank == 0:
+        full = np.full((NX, NY), np.nan)
+        for gx0, gy0, i_lo, i_hi, j_lo, j_hi, ul in gathered:
+            full[gx0 + i_lo:gx0 + i_hi, gy0 + j_lo:gy0 + j_hi] = ul[i_lo:i_hi, j_lo:j_hi]
+        np.savez(out_path, u=full, hist=np.array(hist))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_multiprocess_config5_ingredients(tmp_path, world):
+    """Config 5's cycle (variable coefficient, per-level mixed, W(2,2) red-black GS, fused legs, ghost width 13) over
+    real processes and gloo."""
+    import torch.multiprocessing as mp
+    px, py = D.process_grid(world)
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_var_worker, args=(world, _free_port(), px, py, out), nprocs=world, join=True)
+    res = np.load(out)
+    u_ref, h_ref = _var_oracle(257, 257, len(D.hierarchy_shapes(257, 257, 99)), "W", "rbgs", 1.0, 2, True)
+    np.testing.assert_array_equal(res["u"], u_ref)
+    np.testing.assert_allclose(res["hist"], h_ref, rtol=1e-13)

@@ -60,7 +60,8 @@ def test_virtual_ranks_on_gpu_equal_single_engine(dtype, px, py, NX, NY, agg, cy
     # BASELINE config 4: 8193^2 fp32 on 2 x 2 GPUs (4097^2 + ghost zone each), V(2,2) weighted Jacobi
     ("config4", 2, 2, 8193, 8193, "managed32", "V", "jacobi", 0.8, "fused"),
     # BASELINE config 5's decomposition and cycle: 16385^2, W(2,2) red-black GS, 2 x 4 blocks of 8193 x 4097
-    # (fp64 here: the distributed driver runs one precision on its distributed levels)
+    # (the constant-coefficient fp64 sibling; config 5 as specified -- variable coefficient, per-level mixed -- is
+    # test_config5_as_specified_virtual_ranks below)
     ("config5", 2, 4, 16385, 16385, np.float64, "W", "rbgs", 1.0, "per_operator"),
     ("config5", 2, 4, 16385, 16385, np.float64, "W", "rbgs", 1.0, "fused"),
 ])
@@ -92,6 +93,84 @@ def test_full_size_configs_as_virtual_ranks(name, px, py, NX, NY, dtype, cyc, ki
     for _ in range(2):
         s.cycle(0); hist.append(s.residual_norm())
     u = H.assemble(s, NX, NY, dtype)
+    s.close()
+    assert ref_hist[1] < ref_hist[0]
+    np.testing.assert_allclose(hist, ref_hist, rtol=1e-12)
+    assert np.array_equal(u, u_ref)
+
+
+def _a_at(NX, NY):
+    x, y = np.linspace(0.0, 1.0, NX), np.linspace(0.0, 1.0, NY)
+    return lambda ix, iy: 1.0 + 0.5 * np.sin(2 * np.pi * x[ix])[:, None] * np.cos(2 * np.pi * y[iy])[None, :]
+
+
+@pytest.mark.parametrize("px,py,NX,NY,agg,cyc,kind,omega,mixed", [
+    (2, 2, 513, 513, 129, "V", "jacobi", 0.8, False), (2, 1, 1025, 513, 129, "W", "rbgs", 1.0, False),
+    (2, 2, 1025, 1025, 65, "W", "rbgs", 1.0, True),        # 9 levels, split at 4 (65^2): 1025..129 decomposed in fp64, replicated part mixed
+    (2, 2, 513, 513, 17, "V", "jacobi", 0.8, True),         # 8 levels, split at 4 (33^2), decomposed down to 33^2: an fp32 decomposed level
+    (4, 2, 2049, 1025, 129, "W", "rbgs", 1.15, True)])
+def test_variable_coefficient_mixed_virtual_ranks_equal_single_engine(px, py, NX, NY, agg, cyc, kind, omega, mixed):
+    """-div(a grad u) with per-level mixed precision on the decomposed driver (real kernels, virtual ranks) against the
+    single-GPU engine with the same operator and policy: bit for bit."""
+    import torch
+    rng = np.random.default_rng(NX + NY)
+    rhs = rng.standard_normal((NX, NY))
+    u0 = rng.standard_normal((NX, NY))
+    levels = mg.default_max_levels(NX, NY)
+    a_at = _a_at(NX, NY)
+    eng = mg.MultigridEngine(NX, NY, max_levels=levels, cycle=cyc, smoother=_lib.MG_JACOBI if kind == "jacobi" else _lib.MG_RBGS,
+                             omega=omega, precision=_lib.MG_PREC_MIXED_LEVELS if mixed else _lib.MG_PREC_DOUBLE)
+    eng.set_coefficient(a_at(np.arange(NX), np.arange(NY)))
+    eng.set_rhs(rhs); eng.set_solution(u0)
+    n0_ref = eng.residual_norm()
+    ref_hist = []
+    for _ in range(2):
+        eng.cycle(1); ref_hist.append(eng.residual_norm())
+    u_ref = eng.get_solution()
+    eng.close()
+    ops = D.HipOps(np.float64, torch.device("cuda", 0), mixed=mixed)
+    s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle=cyc, smoother=kind,
+                               omega=omega, agglomerate_at=agg, mode="fused")
+    s.set_coefficient(a_at)
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+    np.testing.assert_allclose(s.residual_norm(), n0_ref, rtol=1e-12)
+    hist = []
+    for _ in range(2):
+        s.cycle(0); hist.append(s.residual_norm())
+    u = H.assemble(s, NX, NY)
+    s.close()
+    np.testing.assert_array_equal(u, u_ref)
+    np.testing.assert_allclose(hist, ref_hist, rtol=1e-12)
+
+
+def test_config5_as_specified_virtual_ranks():
+    """BASELINE config 5 AS SPECIFIED: 2-D variable-coefficient -div(a grad u) = f at 16385^2, per-level mixed precision,
+    W(2,2) red-black GS, 2 x 4 blocks of 8193 x 4097 (+ ghost zone 13) -- all eight ranks as virtual ranks on ONE GPU.
+    The decomposed cycle equals the single-domain engine bit for bit."""
+    import torch
+    NX = NY = 16385
+    px, py = 2, 4
+    rng = np.random.default_rng(11)
+    rhs = rng.standard_normal((NX, NY), dtype=np.float32).astype(np.float64)
+    levels = mg.default_max_levels(NX, NY)
+    a_at = _a_at(NX, NY)
+    eng = mg.MultigridEngine(NX, NY, max_levels=levels, cycle="W", smoother=_lib.MG_RBGS, omega=1.0, precision=_lib.MG_PREC_MIXED_LEVELS)
+    eng.set_coefficient(a_at(np.arange(NX), np.arange(NY)))
+    eng.set_rhs(rhs); eng.set_solution(None)
+    ref_hist = []
+    for _ in range(2):
+        eng.cycle(1); ref_hist.append(eng.residual_norm())
+    u_ref = eng.get_solution()
+    eng.close()
+    ops = D.HipOps(np.float64, torch.device("cuda", 0), mixed=True)
+    s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle="W", smoother="rbgs", omega=1.0, mode="fused")
+    assert s.mode == "fused" and s.G == 13 and s.Ld >= 3 and s.mixed and s.split == levels // 2
+    s.set_coefficient(a_at)
+    s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], None)
+    hist = []
+    for _ in range(2):
+        s.cycle(0); hist.append(s.residual_norm())
+    u = H.assemble(s, NX, NY)
     s.close()
     assert ref_hist[1] < ref_hist[0]
     np.testing.assert_allclose(hist, ref_hist, rtol=1e-12)

@@ -80,24 +80,25 @@ def test_golden_histories_and_solutions(golden_solves, idx):
             rel = np.max(np.abs(u - ref_u)) / np.max(np.abs(ref_u))
             assert rel <= 1e-12, (key, rel)
     elif key.endswith("_mixed__hist"):
+        # per-level mixed: every element-wise operator is bit-exact in both precisions and the coarsest solve stops on the
+        # same sweep, so the iterate is the reference's bit for bit; the norm differs by its fp64 reduction order only
         assert len(hist) == len(ref_hist)
-        np.testing.assert_allclose(hist, ref_hist, rtol=1e-3, atol=1e-12, err_msg=key)
-        ref_u = g[ukey]
-        assert np.max(np.abs(u - ref_u)) / np.max(np.abs(ref_u)) <= 1e-5
+        np.testing.assert_allclose(hist, ref_hist, rtol=1e-12, atol=5e-14, err_msg=key)
+        np.testing.assert_array_equal(u, g[ukey])
     elif key.endswith("_float32__hist"):
-        # fp32 stalls at its round-off floor (~1.9e-3 at 129^2): same decay, same floor
-        k = 3
-        np.testing.assert_allclose(hist[:k], ref_hist[:k], rtol=2e-2, err_msg=key)
-        assert 0.3 < hist[-1] / ref_hist[-1] < 3.0
-        ref_u = g[ukey]
+        # Grid(dtype=float32): the reference reduces its norm in fp32 (pairwise), we accumulate in fp64 -- the only
+        # difference (measured <= 3e-6 relative, tools/fp32_parity_probe.py); the fp32 coarsest solve never meets 1e-12
+        # on either side (1000 sweeps), so the iterate is the reference's bit for bit, stalled at the same floor
+        assert len(hist) == len(ref_hist)
+        np.testing.assert_allclose(hist, ref_hist, rtol=2e-5, err_msg=key)
         assert u.dtype == np.float32
-        assert np.max(np.abs(u - ref_u)) / np.max(np.abs(ref_u)) <= 1e-5
+        np.testing.assert_array_equal(u, g[ukey])
     else:   # adaptive_ref: the reference's own rule drops to fp32 at iteration 1 and never returns (F11)
         assert [p.value for p in pm.precision_history] == list(g[key.replace("__hist", "__precisions")])
-        np.testing.assert_allclose(hist[:3], ref_hist[:3], rtol=2e-2)
-        assert not info["converged"] and 0.3 < hist[-1] / ref_hist[-1] < 3.0
-        ref_u = g[ukey]
-        assert np.max(np.abs(u.astype(np.float64) - ref_u.astype(np.float64))) / np.max(np.abs(ref_u)) <= 1e-5
+        assert len(hist) == len(ref_hist) and not info["converged"]
+        np.testing.assert_allclose(hist, ref_hist, rtol=2e-5, err_msg=key)
+        assert u.dtype == np.float32 and g[ukey].dtype == np.float32
+        np.testing.assert_array_equal(u, g[ukey])
 
 
 def test_info_dict_contract(golden_solves):

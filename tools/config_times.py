@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cycle times of the BASELINE configurations that fit one GPU (device-resident, mg_iterate, tol = 0).
 
-    python3 tools/config_times.py
+    python3 tools/config_times.py [all|const|var]
 """
 import os
 import sys
@@ -21,10 +21,20 @@ CASES = [("config 1 size: 129^2 fp64 V(2,2) Jacobi", 129, "V", _lib.MG_JACOBI, 0
          ("8193^2 adaptive V(2,2) Jacobi", 8193, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_ADAPTIVE, 20),
          ("config 5 on one GPU: 16385^2 mixed W(2,2) red-black GS", 16385, "W", _lib.MG_RBGS, 1.0, _lib.MG_PREC_MIXED_LEVELS, 3),
          ("16385^2 mixed V(2,2) Jacobi", 16385, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_MIXED_LEVELS, 5)]
-for name, n, cyc, sm, omega, prec, its in CASES:
+# variable-coefficient rows (a = 1 + 0.5 sin(2 pi x) cos(2 pi y)): config 5 AS SPECIFIED and its V / Jacobi siblings
+VAR = [("config 5 as specified on one GPU: 16385^2 -div(a grad u) mixed W(2,2) red-black GS", 16385, "W", _lib.MG_RBGS, 1.0, _lib.MG_PREC_MIXED_LEVELS, 3),
+       ("16385^2 -div(a grad u) mixed V(2,2) red-black GS", 16385, "V", _lib.MG_RBGS, 1.0, _lib.MG_PREC_MIXED_LEVELS, 5),
+       ("16385^2 -div(a grad u) mixed V(2,2) Jacobi", 16385, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_MIXED_LEVELS, 5),
+       ("4097^2 -div(a grad u) fp64 V(2,2) Jacobi", 4097, "V", _lib.MG_JACOBI, 0.8, _lib.MG_PREC_DOUBLE, 10),
+       ("4097^2 -div(a grad u) fp64 W(2,2) red-black GS", 4097, "W", _lib.MG_RBGS, 1.0, _lib.MG_PREC_DOUBLE, 5)]
+only = sys.argv[1] if len(sys.argv) > 1 else "all"
+cases = [c + (False,) for c in CASES if only in ("all", "const")] + [c + (True,) for c in VAR if only in ("all", "var")]
+for name, n, cyc, sm, omega, prec, its, var in cases:
     x = np.linspace(0, 1, n)
     rhs = 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
     eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), cycle=cyc, smoother=sm, omega=omega, precision=prec)
+    if var:
+        eng.set_coefficient(1.0 + 0.5 * np.sin(2 * np.pi * x)[:, None] * np.cos(2 * np.pi * x)[None, :])
     eng.set_rhs(rhs)
     eng.set_solution(None)
     eng.iterate(0.0, 2)                                   # warm-up
