@@ -75,8 +75,10 @@ typedef struct mg_config {
   int32_t device;            /* HIP device ordinal                                              */
   int32_t profile;           /* 1: per-level stage timings (synchronising; solvers/multigrid.py:179-182) */
   int32_t colour_offset;     /* parity of the global index of local cell (0,0) (sub-domains)     */
-  int32_t fused;             /* 1: Jacobi cycles run as fused legs (sweeps+residual+restriction / prolongation+sweeps+norm,
-                                two launches per level, identical arithmetic); 0: one launch per operator */
+  int32_t fused;             /* 0: one launch per operator; 1: fused legs (sweeps+residual+restriction / prolongation+sweeps+norm:
+                                two launches per level, identical arithmetic) with the iterate tiled through LDS; 2: the same
+                                legs register-blocked (iterate in registers, DPP lateral neighbours) on levels above ~1100^2
+                                cells, LDS-tiled below; 3: register-blocked on every level (tests) */
   int32_t tail;              /* with fused = 1 -- 1: all levels of <= ~65^2 cells incl. the coarsest solve run in ONE
                                 workgroup with their fields in LDS (one launch per visit); 0: per-level launches */
   int32_t fmg_cycles;        /* > 0: mg_solve without an initial guess starts from a full-multigrid guess with this many

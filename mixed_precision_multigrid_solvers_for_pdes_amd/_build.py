@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmghip.so")
 SOURCES = [os.path.join(CSRC, "mghip.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "mg_kernels.hpp"),
+DEPS = SOURCES + [os.path.join(CSRC, "mg_kernels.hpp"), os.path.join(CSRC, "mg_rb_kernels.hpp"),
                   os.path.join(os.path.dirname(HERE), "include", "mghip.h")]
 # -ffp-contract=off: the kernels reproduce the reference's rounding sequence (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -1391,6 +1391,7 @@ struct FusedArgs {
   // tile selection (overlap of a halo exchange with the tiles that do not need it): 0 all tiles, 1 only tiles whose
   // staged region lies inside [in_i_lo, in_i_hi) x [in_j_lo, in_j_hi), 2 only the others
   int select, in_i_lo, in_i_hi, in_j_lo, in_j_hi;
+  int exp_flags;                // timing experiments (MG_EXP_FLAGS; 0 in production): 1 no XCD remap, 2 column-major tile order
 };
 
 // VAR: the variable-coefficient operator A = coeff * div(a grad .) (see varcoef_kernel above for the discretisation and

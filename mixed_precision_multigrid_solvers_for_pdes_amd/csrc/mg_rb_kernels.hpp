@@ -6,16 +6,19 @@
 //
 //   * a workgroup of W waves owns a region of RI = W * RPT rows x 1 KB; every WAVE owns RPT consecutive rows of it, a
 //     lane the same 16-byte column slot of each: u and rhs of the lane's RPT x N cells stay in registers for the whole
-//     leg, loaded up front (2 RPT 16-byte loads per lane in flight: 16 KB per wave, 128 KB per workgroup -- the
-//     "whole tile at once" access shape that streams at the rate of a copy, profiles/README.md);
+//     leg, loaded up front (2 RPT 16-byte loads per lane in flight: 16 KB per wave -- the "whole tile at once" access
+//     shape that streams at the rate of a copy, profiles/README.md);
 //   * vertical neighbours: rows k -+ 1 of the lane's own strip; across strips the top / bottom row of every wave goes
 //     through a small LDS exchange buffer once per stage (2 writes + 2 reads of 16 bytes per lane and stage instead of
 //     RPT writes + RPT + 2 reads + 2 RPT scalar reads of the LDS-tiled kernel);
 //   * lateral neighbours: lane -+ 1 by DPP wave_shr:1 / wave_shl:1 -- a wave spans the whole region width, so the only
 //     lanes without a neighbour are region-edge lanes, whose cells are halo (stale by construction);
-//   * halo: HALO rows above / below, kRbHL lanes (4 x 16 bytes) left / right: the tile is 56 lanes = 896 bytes = seven
+//   * halo: HALO rows above / below, HL lanes (4 x 16 bytes) left / right: the tile is 56 lanes = 896 bytes = seven
 //     128-byte lines wide, so every tile row starts on a line boundary;
-//   * full weighting in registers too (rows k -+ 1 of the residual strip, DPP for the west column): no LDS r-tile.
+//   * full weighting in registers too (rows k -+ 1 of the residual strip, DPP for the west column): no LDS r-tile;
+//   * the legs are instruction-bound once the data streams (rocprofv3 SQ counters, profiles/README.md): a workgroup
+//     whose region lies strictly inside the grid -- all but the rim of tiles -- takes the INTERIOR body, which drops
+//     every per-cell bounds / boundary / far-edge test and knows row and column parities at compile time.
 //
 // LDS: the exchange buffer (2 x W x 2 KB) and, for the up leg, the coarse patch under the region.
 #pragma once
@@ -24,16 +27,21 @@
 
 namespace mg {
 
-constexpr int kRbHL = 4;                 // halo LANES per side (16 bytes each): tile rows start on 128-byte lines
-
+// Halo LANES per side (16 bytes each).  4: the tile is 56 lanes = 896 bytes = seven 128-byte lines, every tile row starts
+// on a line boundary.  2 (where 2 N cells cover the halo): 60 lanes = 960 bytes, tile rows start on 64-byte boundaries.
+#ifndef MG_RB_HL_MIN
+#define MG_RB_HL_MIN 4
+#endif
 template <typename T, int HALO, int W, int RPT> struct RbShape {
   static constexpr int N = VecW<T>::N;
+  static constexpr int HL = (MG_RB_HL_MIN <= 2 && 2 * N >= HALO) ? 2 : 4;
   static constexpr int RI = W * RPT;                 // region rows
   static constexpr int RJ = 64 * N;                  // region cols (one wave = one region row segment of 1 KB)
   static constexpr int TI = RI - 2 * HALO;           // tile rows
-  static constexpr int TJ = (64 - 2 * kRbHL) * N;    // tile cols
+  static constexpr int TJ = (64 - 2 * HL) * N;       // tile cols
   static_assert(TI > 0 && TI % 2 == 0, "tile height must be even (coarse rows sit on every other tile row)");
-  static_assert(kRbHL * N >= HALO, "lateral halo too narrow");
+  static_assert(RPT % 2 == 0, "rows per wave must be even (row parities are compile-time constants per strip row)");
+  static_assert(HL * N >= HALO, "lateral halo too narrow");
 };
 
 template <typename T> __device__ __forceinline__ T dpp_from_lower_lane(T x);     // lane l receives lane l-1's value (0 for lane 0)
@@ -65,46 +73,31 @@ __device__ __forceinline__ void rb_exchange(Pack<T>* __restrict__ xb, int w, int
   below = (w < W - 1) ? xb[((w + 1) * 2 + 0) * 64 + lane] : zero_pack<T>();
 }
 
-template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int W, int RPT>
-__global__ __launch_bounds__(W * 64) void rb_leg_kernel(
-    const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
-    const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
-    TX* __restrict__ rhs_coarse,          // POST == kPostRestrict: coarse rhs (dtype TX)
-    double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 per block
-    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
+// INT: the region lies strictly inside the grid (and the coarse patch / restriction targets inside the coarse grid, the
+// tile inside the norm window): no per-cell guard survives; only the region's own edge rows are skipped.
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int SM, int W, int RPT, bool INT>
+__device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
+                                            const TX* __restrict__ e_coarse, TX* __restrict__ rhs_coarse,
+                                            double* __restrict__ partials, const FusedArgs& a, T ihx2, T ihy2, T invD, T D, T omega,
+                                            T one_m_omega, T coeff, Pack<T>* __restrict__ xbuf, TX* __restrict__ patch,
+                                            double* __restrict__ red, int i0, int j0) {
   using S = RbShape<T, HALO, W, RPT>;
   constexpr int N = S::N;
   constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
-  constexpr size_t kXBytes = (size_t)2 * W * 2 * 64 * sizeof(Pack<T>);
-  constexpr size_t kPatchBytes = PROLONG ? (size_t)PH * PW * sizeof(TX) : 0;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kXBytes + kPatchBytes];
-  __shared__ double red[W];
-  Pack<T>* const xbuf = reinterpret_cast<Pack<T>*>(lds);
-  TX* const patch = reinterpret_cast<TX*>(lds + kXBytes);
-
-  const int L = xcd_remap(blockIdx.x, a.ntiles);
-  const int ti = L / a.tiles_j, tj = L - ti * a.tiles_j;
-  const int i0 = 1 + ti * S::TI, j0 = tj * S::TJ;
-  const int ri0 = i0 - HALO, rj0 = j0 - kRbHL * N;                // global coords of region cell (0, 0)
-  if (a.select != 0) {
-    const bool inner = ri0 >= a.in_i_lo && ri0 + S::RI <= a.in_i_hi && rj0 >= a.in_j_lo && rj0 + S::RJ <= a.in_j_hi;
-    if ((a.select == 1) != inner) {
-      if (POST == kPostNorm && threadIdx.x == 0) partials[blockIdx.x] = 0.0;
-      return;
-    }
-  }
+  constexpr int kRowPar = (1 - HALO) & 1;                           // parity of the region's first row (tiles start on odd rows, TI even)
+  const int ri0 = i0 - HALO, rj0 = j0 - S::HL * N;                  // global coords of region cell (0, 0); rj0 is even
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int gj0 = rj0 + lane * N;
   const int r_base = w * RPT;
-  const bool col_in = gj0 >= 0 && gj0 < a.nyv;
+  const bool col_in = INT || (gj0 >= 0 && gj0 < a.nyv);
 
   // ---- load: the whole strip at once -----------------------------------------------------------------------------
+  const int pic0 = (ri0 >> 1) + a.ci_off, pjc0 = (rj0 >> 1) + a.cj_off;         // coarse cell of patch entry (0, 0)
   if (PROLONG) {
-    const int pic0 = (ri0 >> 1) + a.ci_off, pjc0 = (rj0 >> 1) + a.cj_off;       // coarse cell of patch entry (0, 0)
     for (int idx = threadIdx.x; idx < PH * PW; idx += W * 64) {
       const int pr = idx / PW, pc = idx - pr * PW;
       const int ic = pic0 + pr, jc = pjc0 + pc;
-      patch[idx] = (ic >= 0 && ic < a.nxc && jc >= 0 && jc < a.nyc) ? e_coarse[(size_t)ic * a.ldc + jc] : TX(0);
+      patch[idx] = (INT || (ic >= 0 && ic < a.nxc && jc >= 0 && jc < a.nyc)) ? e_coarse[(size_t)ic * a.ldc + jc] : TX(0);
     }
   }
   Pack<T> F[RPT], U[RPT];
@@ -113,7 +106,7 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
     const int gi = ri0 + r_base + k;
     F[k] = zero_pack<T>();
     U[k] = zero_pack<T>();
-    if (gi >= 0 && gi < a.nx && col_in) {
+    if (INT || (gi >= 0 && gi < a.nx && col_in)) {
       F[k] = ldg(rhs + (size_t)gi * a.ld + gj0);
       if (!ZERO_INIT) U[k] = ldg(u + (size_t)gi * a.ld + gj0);
     }
@@ -121,18 +114,42 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
   if (PROLONG) {
     __syncthreads();
     using TS = typename std::conditional<(sizeof(TC) > sizeof(T)), TC, T>::type;
-    const int pic0 = (ri0 >> 1) + a.ci_off, pjc0 = (rj0 >> 1) + a.cj_off;
-    const TX* pe = patch - ((ptrdiff_t)pic0 * PW + pjc0);                       // the patch addressed like the coarse array
+    if (INT) {
+      // row / column parities are compile-time constants; entry (pr, pc) of the patch holds coarse (pic0 + pr, pjc0 + pc)
+      constexpr int M = N / 2 + 1;
+      const TX* pl = patch + (r_base / 2) * PW + lane * (N / 2);
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const int gi = ri0 + r_base + k;
-      if (gi >= 0 && gi < a.nx && col_in) {
-        TC val[N];
-        bool ok[N];
-        prolong_vec<TX, TC, N>(pe, PW, a.nxc, a.nyc, gi, gj0, a.nx, a.ny, a.sides, val, ok, a.ci_off, a.cj_off);
+      for (int k = 0; k < RPT; ++k) {
+        const bool iodd = ((kRowPar + k) & 1) != 0;                  // folds per unrolled k
+        const int pr = (k + kRowPar) >> 1;                           // patch row of the coarse row at / above this fine row
+        TC av[M], bv[M];
 #pragma unroll
-        for (int e = 0; e < N; ++e)
-          if (ok[e]) U[k].v[e] = (T)((TS)U[k].v[e] + (TS)val[e]);
+        for (int m = 0; m < M; ++m) {
+          av[m] = (TC)pl[pr * PW + m];
+          bv[m] = iodd ? (TC)pl[(pr + 1) * PW + m] : TC(0);
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const int m = e >> 1;
+          TC val;
+          if ((e & 1) == 0) val = iodd ? TC(0.5) * (av[m] + bv[m]) : av[m];
+          else val = iodd ? TC(0.25) * (((av[m] + av[m + 1]) + bv[m]) + bv[m + 1]) : TC(0.5) * (av[m] + av[m + 1]);
+          U[k].v[e] = (T)((TS)U[k].v[e] + (TS)val);
+        }
+      }
+    } else {
+      const TX* pe = patch - ((ptrdiff_t)pic0 * PW + pjc0);                       // the patch addressed like the coarse array
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int gi = ri0 + r_base + k;
+        if (gi >= 0 && gi < a.nx && col_in) {
+          TC val[N];
+          bool ok[N];
+          prolong_vec<TX, TC, N>(pe, PW, a.nxc, a.nyc, gi, gj0, a.nx, a.ny, a.sides, val, ok, a.ci_off, a.cj_off);
+#pragma unroll
+          for (int e = 0; e < N; ++e)
+            if (ok[e]) U[k].v[e] = (T)((TS)U[k].v[e] + (TS)val[e]);
+        }
       }
     }
   }
@@ -144,6 +161,8 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
     Pack<T> above, below;
     rb_exchange<T, W>(xbuf + (size_t)(stage & 1) * W * 2 * 64, w, lane, U[0], U[RPT - 1], above, below);
     const int colour = s & 1;
+    // parity of (gi + gj + colour_offset) for strip row 0, cell 0: rows and cells alternate from there
+    const int par0 = (ri0 + r_base + gj0 + a.colour_offset) & 1;
     Pack<T> prev = above;                         // the (old) row above the one being updated
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -153,7 +172,9 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
       const T left = dpp_from_lower_lane<T>(mid.v[N - 1]);       // every lane active here
       const T right = dpp_from_upper_lane<T>(mid.v[0]);
       Pack<T> o = mid;
-      if (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+      const bool row_ok = INT ? ((k > 0 || w > 0) && (k < RPT - 1 || w < W - 1))
+                              : (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1);
+      if (row_ok) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
@@ -162,8 +183,8 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
           const T un = a.use_div ? (F[k].v[e] + nb) / D : (F[k].v[e] + nb) * invD;
           const T res = one_m_omega * mid.v[e] + omega * un;
           const int gj = gj0 + e;
-          const bool mine = (SM != kSmRbgs) || (((gi + gj + a.colour_offset) & 1) == colour);
-          if (gj >= 1 && gj < a.ny - 1 && mine) o.v[e] = res;
+          const bool mine = (SM != kSmRbgs) || (((par0 + k + e) & 1) == colour);
+          if ((INT || (gj >= 1 && gj < a.ny - 1)) && mine) o.v[e] = res;
         }
       }
       U[k] = o;
@@ -172,11 +193,11 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
   }
 
   // ---- write the tile of u' ------------------------------------------------------------------------------------------
-  const bool lane_in_tile = lane >= kRbHL && lane < 64 - kRbHL;
+  const bool lane_in_tile = lane >= S::HL && lane < 64 - S::HL;
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     const int r = r_base + k, gi = ri0 + r;
-    if (r >= HALO && r < HALO + S::TI && lane_in_tile && gi < a.nx && gj0 < a.nyv) stg(out + (size_t)gi * a.ld + gj0, U[k]);
+    if (r >= HALO && r < HALO + S::TI && lane_in_tile && (INT || (gi < a.nx && gj0 < a.nyv))) stg(out + (size_t)gi * a.ld + gj0, U[k]);
   }
   if (POST == kPostNone) return;
 
@@ -198,16 +219,18 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
       Pack<T> o = F[k];
       const bool in_tile = r >= HALO && r < HALO + S::TI && lane_in_tile;
       const bool wanted = (POST == kPostRestrict) || in_tile;        // the norm only needs r on the tile itself
-      if (wanted && r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1) {
+      const bool row_ok = INT ? ((k > 0 || w > 0) && (k < RPT - 1 || w < W - 1))
+                              : (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1);
+      if (wanted && row_ok) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
           const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
           const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + wv) * ihy2) - mid.v[e] * D);
           const int gj = gj0 + e;
-          if (gj >= 1 && gj < a.ny - 1) {
+          if (INT || (gj >= 1 && gj < a.ny - 1)) {
             o.v[e] = F[k].v[e] - au;
-            if (POST == kPostNorm && in_tile && gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi)
+            if (POST == kPostNorm && in_tile && (INT || (gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi)))
               acc += (double)o.v[e] * (double)o.v[e];
           }
         }
@@ -231,15 +254,16 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
       const Pack<T> up = (k > 0) ? R[k - 1] : above;
       const Pack<T> mid = R[k];
       const Pack<T> dn = (k < RPT - 1) ? R[k + 1] : below;
+      if (((kRowPar + k) & 1) != 0) continue;                                          // coarse rows sit on even fine rows (folds per k)
       // west neighbours of the lane's first cell, from the lane below (all lanes active)
       const T nw0 = dpp_from_lower_lane<T>(up.v[N - 1]), w0 = dpp_from_lower_lane<T>(mid.v[N - 1]), sw0 = dpp_from_lower_lane<T>(dn.v[N - 1]);
-      if ((fi & 1) || r < HALO || r >= HALO + S::TI || !lane_in_tile) continue;       // coarse rows sit on even fine rows
+      if (r < HALO || r >= HALO + S::TI || !lane_in_tile) continue;
       const int ic = (fi >> 1) + a.ci_off;
-      if (ic < 1 || ic > a.nxc - 2 || fi < 1 || fi > a.nx - 2) continue;
+      if (!INT && (ic < 1 || ic > a.nxc - 2 || fi < 1 || fi > a.nx - 2)) continue;
 #pragma unroll
       for (int e = 0; e < N; e += 2) {                                                 // gj0 is even: e even = coarse column
         const int fj = gj0 + e, jc = (fj >> 1) + a.cj_off;
-        if (jc < 1 || jc > a.nyc - 2 || fj < 1 || fj > a.ny - 2) continue;
+        if (!INT && (jc < 1 || jc > a.nyc - 2 || fj < 1 || fj > a.ny - 2)) continue;
         const T NWv = (e == 0) ? nw0 : up.v[e > 0 ? e - 1 : 0], Wv = (e == 0) ? w0 : mid.v[e > 0 ? e - 1 : 0],
                 SWv = (e == 0) ? sw0 : dn.v[e > 0 ? e - 1 : 0];
         const T corners = ((NWv + up.v[e + 1]) + SWv) + dn.v[e + 1];
@@ -248,6 +272,54 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
       }
     }
   }
+}
+
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int W, int RPT>
+__global__ __launch_bounds__(W * 64) void rb_leg_kernel(
+    const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
+    const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
+    TX* __restrict__ rhs_coarse,          // POST == kPostRestrict: coarse rhs (dtype TX)
+    double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 per block
+    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
+  using S = RbShape<T, HALO, W, RPT>;
+  constexpr int N = S::N;
+  constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
+  constexpr size_t kXBytes = (size_t)2 * W * 2 * 64 * sizeof(Pack<T>);
+  constexpr size_t kPatchBytes = PROLONG ? (size_t)PH * PW * sizeof(TX) : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kXBytes + kPatchBytes];
+  __shared__ double red[W];
+  Pack<T>* const xbuf = reinterpret_cast<Pack<T>*>(lds);
+  TX* const patch = reinterpret_cast<TX*>(lds + kXBytes);
+
+  const int L = (a.exp_flags & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, a.ntiles);
+  const int tiles_i = a.ntiles / a.tiles_j;
+  const int ti = (a.exp_flags & 2) ? L % tiles_i : L / a.tiles_j, tj = (a.exp_flags & 2) ? L / tiles_i : L - ti * a.tiles_j;
+  const int i0 = 1 + ti * S::TI, j0 = tj * S::TJ;
+  const int ri0 = i0 - HALO, rj0 = j0 - S::HL * N;                // global coords of region cell (0, 0)
+  if (a.select != 0) {
+    const bool inner = ri0 >= a.in_i_lo && ri0 + S::RI <= a.in_i_hi && rj0 >= a.in_j_lo && rj0 + S::RJ <= a.in_j_hi;
+    if ((a.select == 1) != inner) {
+      if (POST == kPostNorm && threadIdx.x == 0) partials[blockIdx.x] = 0.0;
+      return;
+    }
+  }
+  // the region strictly inside the grid, the coarse patch inside the coarse grid, restriction targets interior coarse
+  // cells, the tile inside the norm window: the guard-free body
+  bool interior = !(a.exp_flags & 4) && ri0 >= 1 && ri0 + S::RI <= a.nx - 1 && rj0 >= 1 && rj0 + S::RJ <= a.ny - 1;
+  if (PROLONG) {
+    const int pic0 = (ri0 >> 1) + a.ci_off, pjc0 = (rj0 >> 1) + a.cj_off;
+    interior = interior && pic0 >= 0 && pic0 + PH <= a.nxc && pjc0 >= 0 && pjc0 + PW <= a.nyc;
+  }
+  if (POST == kPostNorm) interior = interior && i0 >= a.ni_lo && i0 + S::TI <= a.ni_hi && j0 >= a.nj_lo && j0 + S::TJ <= a.nj_hi;
+  if (POST == kPostRestrict)
+    interior = interior && ((i0 + 1) >> 1) + a.ci_off >= 1 && ((i0 + S::TI - 1) >> 1) + a.ci_off <= a.nxc - 2 &&
+               (j0 >> 1) + a.cj_off >= 1 && ((j0 + S::TJ - 2) >> 1) + a.cj_off <= a.nyc - 2;
+  if (interior)
+    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, true>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD,
+                                                                           D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0);
+  else
+    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, false>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD,
+                                                                            D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0);
 }
 
 }  // namespace mg

@@ -2,6 +2,7 @@
 // device-resident V/W/F-cycle driver (reference: solvers/multigrid.py:184-337, gpu/gpu_solver.py:186-446).
 // No Python, no torch types: plain pointers and sizes.
 #include "mg_kernels.hpp"
+#include "mg_rb_kernels.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -10,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -318,6 +320,8 @@ mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int n
   a.ci_off = a.cj_off = 0; a.sides = mg::kAllSides;
   a.ni_lo = 1; a.ni_hi = nx - 1; a.nj_lo = 1; a.nj_hi = ny - 1;
   a.select = 0; a.in_i_lo = a.in_j_lo = 0; a.in_i_hi = a.in_j_hi = 0;
+  static const int flags = [] { const char* e = std::getenv("MG_EXP_FLAGS"); return e ? std::atoi(e) : 0; }();
+  a.exp_flags = flags;
   return a;
 }
 
@@ -332,6 +336,7 @@ struct LegGeom {      // what every fused launch needs
   int select = 0, in_i_lo = 0, in_i_hi = 0, in_j_lo = 0, in_j_hi = 0;   // tile selection (see mg::FusedArgs)
   double sigma = 0.0;                                                    // Helmholtz shift (see coefs)
   const void* acoef = nullptr;                                           // variable coefficient: vertex values (dtype / pitch of u)
+  int rb = 0;                                                            // 1: register-blocked legs on the bandwidth-bound levels
 };
 inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
   a.ci_off = g.ci_off; a.cj_off = g.cj_off; a.sides = g.sides;
@@ -426,8 +431,96 @@ void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, 
   else launch_sweeps_ti<T, SM, mg::kFusedTI>(u, rhs, out, g, st);
 }
 
+// ---- register-blocked legs (mg_rb_kernels.hpp): constant coefficients, levels above ~1100^2 cells ------------------
+// Workgroup shape (waves x rows per wave).  MG_RB_SHAPE selects among the compiled shapes at run time (experiments).
+#ifndef MG_RB_SHAPES
+#define MG_RB_SHAPES 2
+#endif
+inline int rb_shape() {
+  static const int s = [] { const char* e = std::getenv("MG_RB_SHAPE"); return e ? std::atoi(e) : 0; }();
+  return (s >= 0 && s < MG_RB_SHAPES) ? s : 0;
+}
+template <typename T, int HALO, int W, int RPT>
+mg::FusedArgs rb_args(const LegGeom& g, bool use_div) {
+  using S = mg::RbShape<T, HALO, W, RPT>;
+  mg::FusedArgs a = fused_args<T, HALO, mg::kFusedTI>(g.nx, g.ny, g.ld, g.nsweep, use_div, g.nxc, g.nyc, g.ldc, g.poff);
+  const int tiles_i = (g.nx - 2 + S::TI - 1) / S::TI;
+  a.tiles_j = (g.ny - 1 + S::TJ - 1) / S::TJ;
+  a.ntiles = tiles_i * a.tiles_j;
+  apply_sub(a, g);
+  return a;
+}
+// g.rb: 0 never, 1 on levels above ~1100^2 cells (where a launch is bandwidth-bound), 2 on every level (tests)
+inline bool use_rb(const LegGeom& g, int sm) { return !g.acoef && (g.rb == 2 || (g.rb == 1 && !small_tiles(g, sm))); }
+
+template <typename T, typename TX, int SM, int W, int RPT>
+void launch_down_rb_s(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
+  constexpr int HALO = 2 * mg::sweep_halo(SM) + 2;
+  const Coef c = coefs(g.hx, g.hy, g.sigma);
+  const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
+  auto k = zero_init ? mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM, W, RPT>
+                     : mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 1, SM, W, RPT>;
+  hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr, (TX*)rhs_c,
+                     (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+}
+template <typename T, typename TX, typename TC, int SM, int W, int RPT>
+int launch_up_rb_s(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm, hipStream_t st) {
+  const Coef c = coefs(g.hx, g.hy, g.sigma);
+  if (norm) {
+    constexpr int HALO = 2 * mg::sweep_halo(SM) + 1;
+    const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
+    hipLaunchKernelGGL((mg::rb_leg_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM, W, RPT>), dim3(a.ntiles), dim3(W * 64), 0, st,
+                       (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c, (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
+                       (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+    return a.ntiles;
+  }
+  constexpr int HALO = 2 * mg::sweep_halo(SM);
+  const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
+  hipLaunchKernelGGL((mg::rb_leg_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM, W, RPT>), dim3(a.ntiles), dim3(W * 64), 0, st,
+                     (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c, (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
+                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+  return 0;
+}
+template <typename T, int SM, int W, int RPT>
+void launch_sweeps_rb_s(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
+  constexpr int HALO = 2 * mg::sweep_halo(SM);
+  const Coef c = coefs(g.hx, g.hy, g.sigma);
+  const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
+  hipLaunchKernelGGL((mg::rb_leg_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM, W, RPT>), dim3(a.ntiles), dim3(W * 64), 0, st,
+                     (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr, (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
+                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0);
+}
+// shape table: 0 = 4 waves x 8 rows (four workgroups per CU: the best overlap of loads and arithmetic measured), 1 = 8 x 8
+#if MG_RB_SHAPES > 1
+#define MG_RB_DISPATCH(CALL4x8, CALL8x8) \
+  switch (rb_shape()) { case 1: CALL8x8; break; default: CALL4x8; }
+#else
+#define MG_RB_DISPATCH(CALL4x8, CALL8x8) CALL4x8;
+#endif
+template <typename T, typename TX, int SM>
+void launch_down_rb(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
+  MG_RB_DISPATCH((launch_down_rb_s<T, TX, SM, 4, 8>(u, rhs, out, rhs_c, g, zero_init, st)), (launch_down_rb_s<T, TX, SM, 8, 8>(u, rhs, out, rhs_c, g, zero_init, st)))
+}
+template <typename T, typename TX, typename TC, int SM>
+int launch_up_rb(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm, hipStream_t st) {
+  int n = 0;
+  MG_RB_DISPATCH((n = launch_up_rb_s<T, TX, TC, SM, 4, 8>(u, rhs, out, e_c, partials, g, norm, st)), (n = launch_up_rb_s<T, TX, TC, SM, 8, 8>(u, rhs, out, e_c, partials, g, norm, st)))
+  return n;
+}
+template <typename T, int SM>
+void launch_sweeps_rb(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
+  MG_RB_DISPATCH((launch_sweeps_rb_s<T, SM, 4, 8>(u, rhs, out, g, st)), (launch_sweeps_rb_s<T, SM, 8, 8>(u, rhs, out, g, st)))
+}
+
 template <int SM>
 void d_down_sm(int dt, int dx, const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
+  if (use_rb(g, SM)) {
+    if (dt == MG_F32 && dx == MG_F32) launch_down_rb<float, float, SM>(u, rhs, out, rhs_c, g, zero_init, st);
+    else if (dt == MG_F64 && dx == MG_F64) launch_down_rb<double, double, SM>(u, rhs, out, rhs_c, g, zero_init, st);
+    else if (dt == MG_F64 && dx == MG_F32) launch_down_rb<double, float, SM>(u, rhs, out, rhs_c, g, zero_init, st);
+    else launch_down_rb<float, double, SM>(u, rhs, out, rhs_c, g, zero_init, st);
+    return;
+  }
   if (dt == MG_F32 && dx == MG_F32) launch_down<float, float, SM>(u, rhs, out, rhs_c, g, zero_init, st);
   else if (dt == MG_F64 && dx == MG_F64) launch_down<double, double, SM>(u, rhs, out, rhs_c, g, zero_init, st);
   else if (dt == MG_F64 && dx == MG_F32) launch_down<double, float, SM>(u, rhs, out, rhs_c, g, zero_init, st);
@@ -442,6 +535,16 @@ void d_down(int sm, int dt, int dx, const void* u, const void* rhs, void* out, v
 template <int SM>
 int d_up_sm(int dt, int dx, int dcomp, const void* u, const void* rhs, void* out, const void* e_c, double* partials,
             const LegGeom& g, bool norm, hipStream_t st) {
+  if (use_rb(g, SM)) {
+    if (dcomp == MG_F32) {
+      if (dt == MG_F32 && dx == MG_F32) return launch_up_rb<float, float, float, SM>(u, rhs, out, e_c, partials, g, norm, st);
+      return -1;
+    }
+    if (dt == MG_F64 && dx == MG_F64) return launch_up_rb<double, double, double, SM>(u, rhs, out, e_c, partials, g, norm, st);
+    if (dt == MG_F64 && dx == MG_F32) return launch_up_rb<double, float, double, SM>(u, rhs, out, e_c, partials, g, norm, st);
+    if (dt == MG_F32 && dx == MG_F64) return launch_up_rb<float, double, double, SM>(u, rhs, out, e_c, partials, g, norm, st);
+    return launch_up_rb<float, float, double, SM>(u, rhs, out, e_c, partials, g, norm, st);
+  }
   if (dcomp == MG_F32) {
     if (dt == MG_F32 && dx == MG_F32) return launch_up<float, float, float, SM>(u, rhs, out, e_c, partials, g, norm, st);
     return -1;
@@ -457,6 +560,11 @@ int d_up(int sm, int dt, int dx, int dcomp, const void* u, const void* rhs, void
                        : d_up_sm<mg::kSmJacobi>(dt, dx, dcomp, u, rhs, out, e_c, partials, g, norm, st);
 }
 void d_sweeps(int sm, int dt, const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
+  if (use_rb(g, sm == MG_RBGS ? mg::kSmRbgs : mg::kSmJacobi)) {
+    if (sm == MG_RBGS) { if (dt == MG_F32) launch_sweeps_rb<float, mg::kSmRbgs>(u, rhs, out, g, st); else launch_sweeps_rb<double, mg::kSmRbgs>(u, rhs, out, g, st); }
+    else { if (dt == MG_F32) launch_sweeps_rb<float, mg::kSmJacobi>(u, rhs, out, g, st); else launch_sweeps_rb<double, mg::kSmJacobi>(u, rhs, out, g, st); }
+    return;
+  }
   if (sm == MG_RBGS) {
     if (dt == MG_F32) launch_sweeps<float, mg::kSmRbgs>(u, rhs, out, g, st); else launch_sweeps<double, mg::kSmRbgs>(u, rhs, out, g, st);
   } else {
@@ -574,6 +682,10 @@ struct mg_handle {
 };
 
 namespace {
+
+// cfg.fused: 0 one launch per operator, 1 LDS-tiled fused legs, 2 register-blocked legs on the large levels (LDS-tiled
+// below), 3 register-blocked legs on every level
+inline int rb_mode(const mg_handle* h) { return h->cfg.fused == 2 ? 1 : (h->cfg.fused == 3 ? 2 : 0); }
 
 // hipMemset on device memory is asynchronous to the host and runs on the NULL stream, which a
 // hipStreamNonBlocking stream does not wait for: zero on the stream that will use the memory.
@@ -812,6 +924,7 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   const int sm = h->cfg.smoother;
   LegGeom g{f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, 0, h->cfg.colour_offset, fine};
   g.sigma = h->sigma;
+  g.rb = rb_mode(h);
   if (h->varcoef) g.acoef = f.a[dt];
   if (part != kPartBack) {
     StageTimer tm(h, &f, 0);
@@ -1526,6 +1639,7 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
   if ((op == 0 || op == 10) && h->cfg.smoother != MG_JACOBI) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
   if ((op == 0 || (op >= 7 && op <= 9)) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no ping-pong buffer on this level");
   if ((op == 2 || op == 4 || op == 5 || op == 7 || op == 8) && (level >= h->L() - 1 || !v.r[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no coarser level");
+  static const int exp_nsweep = [] { const char* e = std::getenv("MG_EXP_NSWEEP"); return e ? std::atoi(e) : 2; }();
   h->norm_partials = 0;
   // op 10: the single-sweep Jacobi kernel rotating over independent {u, rhs, out} sets whose total exceeds three
   // times the 256 MiB Infinity Cache, so that no launch finds its operands on die: the HBM-proper smoother figure
@@ -1562,14 +1676,14 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
                   if (d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], v.u[dt], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE; } break;
         case 6: { const int rc = run_cycle(h); if (rc != MG_OK) return rc; } break;
         case 7: { Level& c = h->lv[level + 1]; const int dc = c.rhs[dt] ? dt : 1 - dt;          // down leg
-                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma;
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h);
                   d_down(h->cfg.smoother, dt, dc, v.u[dt], v.rhs[dt], v.t[dt], c.rhs[dc], g, false, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         case 8: { Level& c = h->lv[level + 1]; const int dc = c.u[dt] ? dt : 1 - dt;            // up leg (+ norm on level 0)
-                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma;
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h);
                   if (d_up(h->cfg.smoother, dt, dc, h->grid_dtype, v.u[dt], v.rhs[dt], v.t[dt], c.u[dc], h->partials, g, level == 0, h->stream) < 0) return MG_ERR_INVALID_VALUE;
                   std::swap(v.u[dt], v.t[dt]); } break;
-        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, 2, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma;
+        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h);
                   d_sweeps(h->cfg.smoother, dt, v.u[dt], v.rhs[dt], v.t[dt], g, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         default: return MG_ERR_INVALID_VALUE;
@@ -1682,6 +1796,7 @@ int mg_dev_down_leg_var(int smoother, int dtype, int coarse_dtype, int nx, int n
   CHECK_DEV(select >= 0 && select <= 2 && (select == 0 || inner_rect), "mg_dev_down_leg: bad tile selection");
   if (select) { g.select = select; g.in_i_lo = inner_rect[0]; g.in_i_hi = inner_rect[1]; g.in_j_lo = inner_rect[2]; g.in_j_hi = inner_rect[3]; }
   g.acoef = acoef;
+  g.rb = 1;                       // register-blocked legs on blocks above ~1100^2 cells (same results, mg_config.fused = 2)
   d_down(smoother, dtype, coarse_dtype, u ? u : rhs, rhs, out, rhs_coarse, g, zero_init != 0, (hipStream_t)stream);
   HIPC(nullptr, hipGetLastError());
   return MG_OK;
@@ -1708,6 +1823,7 @@ int mg_dev_up_leg_var(int smoother, int dtype, int coarse_dtype, int compute_dty
   g.ci_off = ci_off; g.cj_off = cj_off; g.sides = sides;
   if (norm) { g.ni_lo = ni_lo; g.ni_hi = ni_hi; g.nj_lo = nj_lo; g.nj_hi = nj_hi; }
   g.acoef = acoef;
+  g.rb = 1;
   const int n = d_up(smoother, dtype, coarse_dtype, compute_dtype, u, rhs, out, e_coarse, (double*)scratch, g, norm != 0, (hipStream_t)stream);
   if (n < 0) return fail(nullptr, MG_ERR_INVALID_VALUE, "mg_dev_up_leg: fp32 interpolation needs fp32 coarse and fine fields");
   if (norm) launch_reduce((double*)scratch, n, sumsq_dev, (hipStream_t)stream);

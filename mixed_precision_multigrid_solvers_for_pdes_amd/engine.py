@@ -12,9 +12,11 @@ class MultigridEngine:
     def __init__(self, nx, ny, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0, max_levels=4, cycle="V", pre=2, post=2,
                  smoother=_lib.MG_JACOBI, omega=0.8, coarse_tol=1e-12, coarse_maxit=1000,
                  precision=_lib.MG_PREC_DOUBLE, switch_threshold=1e-6, memory_threshold_gb=4.0,
-                 adaptive_reference_rule=False, device=0, profile=False, colour_offset=0, fused=True, tail=True, speculate=True, fmg_cycles=0,
+                 adaptive_reference_rule=False, device=0, profile=False, colour_offset=0, fused=2, tail=True, speculate=True, fmg_cycles=0,
                  mixed_split=0):
         lib = _lib.load()
+        # fused: 0 / False one launch per operator; 1 / True fused legs tiled through LDS; 2 (default) the same legs
+        # register-blocked on levels above ~1100^2 cells; 3 register-blocked on every level (include/mghip.h mg_config.fused)
         if isinstance(cycle, str):
             if cycle not in _lib.CYCLES:
                 raise ValueError(f"unknown cycle type {cycle!r}")
@@ -23,7 +25,7 @@ class MultigridEngine:
                             float(coeff), int(max_levels), int(cycle), int(pre), int(post), int(smoother),
                             float(omega), float(coarse_tol), int(coarse_maxit), int(precision),
                             float(switch_threshold), float(memory_threshold_gb), int(bool(adaptive_reference_rule)),
-                            int(device), int(bool(profile)), int(colour_offset), int(bool(fused)), int(bool(tail)), int(fmg_cycles), int(bool(speculate)),
+                            int(device), int(bool(profile)), int(colour_offset), int(fused), int(bool(tail)), int(fmg_cycles), int(bool(speculate)),
                             int(mixed_split))
         self.cfg = cfg
         self._h = C.c_void_p(None)

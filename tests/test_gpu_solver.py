@@ -192,6 +192,36 @@ def test_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post, sm, o
     assert rf["precision_codes"] == ru["precision_codes"] == rt["precision_codes"]
 
 
+@pytest.mark.parametrize("sm,omega", [("jacobi", 0.8), ("rbgs", 1.0), ("rbgs", 1.15)])
+@pytest.mark.parametrize("prec", ["double", "single", "mixed", "adaptive"])
+@pytest.mark.parametrize("n,cyc,pre,post", [(257, "V", 2, 2), (129, "W", 2, 2), (513, "V", 1, 1), (129, "V", 3, 0), (65, "F", 0, 4),
+                                            ((97, 193), "V", 2, 1), ((449, 131), "V", 2, 2), (2049, "V", 2, 2)])
+def test_register_blocked_legs_equal_lds_tiled_legs(prec, n, cyc, pre, post, sm, omega):
+    """fused = 3 runs every level on the register-blocked legs (iterate in registers, strip edges through a small LDS
+    exchange, lateral neighbours by DPP, full weighting in registers), fused = 2 the large levels only: both must
+    reproduce the LDS-tiled legs (fused = 1, themselves equal to one launch per operator) bit for bit."""
+    nx, ny = (n, n) if isinstance(n, int) else n
+    code = {"double": _lib.MG_PREC_DOUBLE, "single": _lib.MG_PREC_SINGLE, "mixed": _lib.MG_PREC_MIXED_LEVELS,
+            "adaptive": _lib.MG_PREC_ADAPTIVE}[prec]
+    rng = np.random.default_rng(nx + 3 * ny + pre)
+    rhs = O.sine_rhs(nx, ny) + 0.05 * rng.standard_normal((nx, ny))
+    u0 = rng.standard_normal((nx, ny))
+    res = []
+    for fused in (3, 2, 1):
+        eng = mg.MultigridEngine(nx, ny, max_levels=mg.default_max_levels(nx, ny), cycle=cyc, pre=pre, post=post,
+                                 smoother=_lib.MG_JACOBI if sm == "jacobi" else _lib.MG_RBGS, omega=omega, precision=code,
+                                 switch_threshold=1e-3, coarse_maxit=60, fused=fused)
+        u, r = eng.solve(rhs, u0, tol=1e-30, max_iterations=4)
+        eng.close()
+        res.append((u, r))
+    (u3, r3), (u2, r2), (u1, r1) = res
+    np.testing.assert_array_equal(u3, u1)
+    np.testing.assert_array_equal(u2, u1)
+    np.testing.assert_allclose(r3["residual_history"], r1["residual_history"], rtol=1e-11)
+    np.testing.assert_allclose(r2["residual_history"], r1["residual_history"], rtol=1e-11)
+    assert r3["precision_codes"] == r1["precision_codes"]
+
+
 @pytest.mark.parametrize("prec,thr", [("double", 1e-6), ("adaptive", 1e-3), ("adaptive", 1e-6), ("mixed", 1e-6)])
 def test_speculative_launching_changes_nothing(prec, thr):
     """mg_iterate queues the front part of cycle k+1 while ||r_k|| is in flight; stopping on tolerance and precision
@@ -308,7 +338,7 @@ def test_config5_size_16385_mixed_w_rbgs_single_gpu():
     x = np.linspace(0.0, 1.0, n)
     rhs = (2 * np.pi**2) * np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
     out = []
-    for fused in (True, False):
+    for fused in (2, 0):          # register-blocked legs on the large levels (LDS-tiled below, LDS tail) vs one launch per operator
         eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), cycle="W", smoother=_lib.MG_RBGS, omega=1.0,
                                  precision=_lib.MG_PREC_MIXED_LEVELS, fused=fused)
         u, r = eng.solve(rhs, tol=0.0, max_iterations=3)

@@ -12,11 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mixed_precision_multigrid_solvers_for_pdes_amd as mg          # noqa: E402
 from mixed_precision_multigrid_solvers_for_pdes_amd import _lib      # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 8193
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4097
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 x = np.linspace(0, 1, n)
 rhs = 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
-eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), precision=_lib.MG_PREC_ADAPTIVE)
+FUSED = int(os.environ.get("MG_FUSED", "1"))      # 1 LDS-tiled, 2 register-blocked on large levels, 3 register-blocked everywhere
+eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), precision=_lib.MG_PREC_ADAPTIVE, fused=FUSED)
 eng.set_rhs(rhs)
 eng.set_solution(None)
 eng.cycle(1)
