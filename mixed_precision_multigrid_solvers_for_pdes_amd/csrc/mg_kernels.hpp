@@ -50,6 +50,17 @@ template <typename T> __device__ __forceinline__ Pack<T> ldg(const T* p) {
 template <typename T> __device__ __forceinline__ void stg(T* p, const Pack<T>& x) {
   *reinterpret_cast<Pack<T>*>(p) = x;
 }
+// 16-byte store with the non-temporal hint (global_store_dwordx4 ... nt): a leg's output tile is not read again before
+// the whole coarser cycle has streamed through the caches
+template <typename T> __device__ __forceinline__ void stg_nt(T* p, const Pack<T>& x) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(*reinterpret_cast<const v4i*>(&x), reinterpret_cast<v4i*>(p));
+}
+template <typename T> __device__ __forceinline__ Pack<T> ldg_nt(const T* p) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
+  return *reinterpret_cast<const Pack<T>*>(&v);
+}
 template <typename T> __device__ __forceinline__ Pack<T> zero_pack() {
   Pack<T> z;
 #pragma unroll
@@ -1391,7 +1402,9 @@ struct FusedArgs {
   // tile selection (overlap of a halo exchange with the tiles that do not need it): 0 all tiles, 1 only tiles whose
   // staged region lies inside [in_i_lo, in_i_hi) x [in_j_lo, in_j_hi), 2 only the others
   int select, in_i_lo, in_i_hi, in_j_lo, in_j_hi;
-  int exp_flags;                // timing experiments (MG_EXP_FLAGS; 0 in production): 1 no XCD remap, 2 column-major tile order
+  int exp_flags;                // bit 3 (8): non-temporal stores of the output tile, bit 4 (16): non-temporal loads of u, bit 5 (32) of rhs
+                                // (set by the launcher for arrays that cannot stay in the 256 MiB Infinity Cache between two legs);
+                                // timing experiments (MG_EXP_FLAGS): 1 no XCD remap, 2 column-major tile order, 4 no interior body
 };
 
 // VAR: the variable-coefficient operator A = coeff * div(a grad .) (see varcoef_kernel above for the discretisation and

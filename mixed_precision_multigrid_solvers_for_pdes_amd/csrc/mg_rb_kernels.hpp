@@ -44,6 +44,9 @@ template <typename T, int HALO, int W, int RPT> struct RbShape {
   static_assert(HL * N >= HALO, "lateral halo too narrow");
 };
 
+#ifndef MG_RB_NT_MODE
+#define MG_RB_NT_MODE 3          // stores + loads of u (measured best at 4097^2 fp64, profiles/README.md)
+#endif
 template <typename T> __device__ __forceinline__ T dpp_from_lower_lane(T x);     // lane l receives lane l-1's value (0 for lane 0)
 template <typename T> __device__ __forceinline__ T dpp_from_upper_lane(T x);     // lane l receives lane l+1's value (0 for lane 63)
 template <> __device__ __forceinline__ float dpp_from_lower_lane<float>(float x) {
@@ -75,7 +78,11 @@ __device__ __forceinline__ void rb_exchange(Pack<T>* __restrict__ xb, int w, int
 
 // INT: the region lies strictly inside the grid (and the coarse patch / restriction targets inside the coarse grid, the
 // tile inside the norm window): no per-cell guard survives; only the region's own edge rows are skipped.
-template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int SM, int W, int RPT, bool INT>
+// NT (compile time -- behind a run-time flag the compiler merges the two stores and drops the hint): bit 0 non-temporal
+// stores of the output tile, bit 1 non-temporal loads of u, bit 2 of rhs.  For arrays that cannot stay in the 256 MiB
+// Infinity Cache from one leg to the next (4097^2 fp64: u, t and rhs are 3 x 136 MB) the hints keep the streamed
+// operands from evicting each other; arrays that do fit (4097^2 fp32) are faster without them.
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int SM, int W, int RPT, bool INT, int NT>
 __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
                                             const TX* __restrict__ e_coarse, TX* __restrict__ rhs_coarse,
                                             double* __restrict__ partials, const FusedArgs& a, T ihx2, T ihy2, T invD, T D, T omega,
@@ -107,8 +114,8 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
     F[k] = zero_pack<T>();
     U[k] = zero_pack<T>();
     if (INT || (gi >= 0 && gi < a.nx && col_in)) {
-      F[k] = ldg(rhs + (size_t)gi * a.ld + gj0);
-      if (!ZERO_INIT) U[k] = ldg(u + (size_t)gi * a.ld + gj0);
+      F[k] = (NT & 4) ? ldg_nt(rhs + (size_t)gi * a.ld + gj0) : ldg(rhs + (size_t)gi * a.ld + gj0);
+      if (!ZERO_INIT) U[k] = (NT & 2) ? ldg_nt(u + (size_t)gi * a.ld + gj0) : ldg(u + (size_t)gi * a.ld + gj0);
     }
   }
   if (PROLONG) {
@@ -197,7 +204,9 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     const int r = r_base + k, gi = ri0 + r;
-    if (r >= HALO && r < HALO + S::TI && lane_in_tile && (INT || (gi < a.nx && gj0 < a.nyv))) stg(out + (size_t)gi * a.ld + gj0, U[k]);
+    if (r >= HALO && r < HALO + S::TI && lane_in_tile && (INT || (gi < a.nx && gj0 < a.nyv))) {
+      if (NT & 1) stg_nt(out + (size_t)gi * a.ld + gj0, U[k]); else stg(out + (size_t)gi * a.ld + gj0, U[k]);
+    }
   }
   if (POST == kPostNone) return;
 
@@ -283,6 +292,7 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
     FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
   using S = RbShape<T, HALO, W, RPT>;
   constexpr int N = S::N;
+  constexpr int kNT = (TAG == 2) ? MG_RB_NT_MODE : 0;           // TAG 2: the streaming-hint variant for arrays beyond the Infinity Cache
   constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
   constexpr size_t kXBytes = (size_t)2 * W * 2 * 64 * sizeof(Pack<T>);
   constexpr size_t kPatchBytes = PROLONG ? (size_t)PH * PW * sizeof(TX) : 0;
@@ -315,10 +325,10 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
     interior = interior && ((i0 + 1) >> 1) + a.ci_off >= 1 && ((i0 + S::TI - 1) >> 1) + a.ci_off <= a.nxc - 2 &&
                (j0 >> 1) + a.cj_off >= 1 && ((j0 + S::TJ - 2) >> 1) + a.cj_off <= a.nyc - 2;
   if (interior)
-    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, true>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD,
+    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, true, kNT>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD,
                                                                            D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0);
   else
-    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, false>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD,
+    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, false, kNT>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD,
                                                                             D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0);
 }
 

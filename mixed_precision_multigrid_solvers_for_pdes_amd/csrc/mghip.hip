@@ -434,7 +434,7 @@ void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, 
 // ---- register-blocked legs (mg_rb_kernels.hpp): constant coefficients, levels above ~1100^2 cells ------------------
 // Workgroup shape (waves x rows per wave).  MG_RB_SHAPE selects among the compiled shapes at run time (experiments).
 #ifndef MG_RB_SHAPES
-#define MG_RB_SHAPES 2
+#define MG_RB_SHAPES 1
 #endif
 inline int rb_shape() {
   static const int s = [] { const char* e = std::getenv("MG_RB_SHAPE"); return e ? std::atoi(e) : 0; }();
@@ -453,13 +453,23 @@ mg::FusedArgs rb_args(const LegGeom& g, bool use_div) {
 // g.rb: 0 never, 1 on levels above ~1100^2 cells (where a launch is bandwidth-bound), 2 on every level (tests)
 inline bool use_rb(const LegGeom& g, int sm) { return !g.acoef && (g.rb == 2 || (g.rb == 1 && !small_tiles(g, sm))); }
 
+// Arrays of more than ~100 MB cannot stay in the 256 MiB Infinity Cache from one leg to the next (u, t and rhs compete):
+// their legs run with streaming hints (rb_leg_kernel TAG 2).  MG_RB_NT=0/1 overrides (experiments).
+inline bool rb_stream(const LegGeom& g, size_t esz) {
+  static const int force = [] { const char* e = std::getenv("MG_RB_NT"); return e ? std::atoi(e) : -1; }();
+  if (force >= 0) return force != 0;
+  return (size_t)g.nx * g.ld * esz > (size_t)100 << 20;
+}
 template <typename T, typename TX, int SM, int W, int RPT>
 void launch_down_rb_s(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
   constexpr int HALO = 2 * mg::sweep_halo(SM) + 2;
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
-  auto k = zero_init ? mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM, W, RPT>
-                     : mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 1, SM, W, RPT>;
+  const bool nt = rb_stream(g, sizeof(T));
+  auto k = zero_init ? (nt ? mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 2, SM, W, RPT>
+                           : mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM, W, RPT>)
+                     : (nt ? mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 2, SM, W, RPT>
+                           : mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 1, SM, W, RPT>);
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr, (TX*)rhs_c,
                      (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
 }
@@ -469,14 +479,18 @@ int launch_up_rb_s(const void* u, const void* rhs, void* out, const void* e_c, d
   if (norm) {
     constexpr int HALO = 2 * mg::sweep_halo(SM) + 1;
     const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
-    hipLaunchKernelGGL((mg::rb_leg_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM, W, RPT>), dim3(a.ntiles), dim3(W * 64), 0, st,
+    auto k = rb_stream(g, sizeof(T)) ? mg::rb_leg_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 2, SM, W, RPT>
+                                     : mg::rb_leg_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM, W, RPT>;
+    hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                        (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c, (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
                        (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
     return a.ntiles;
   }
   constexpr int HALO = 2 * mg::sweep_halo(SM);
   const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
-  hipLaunchKernelGGL((mg::rb_leg_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM, W, RPT>), dim3(a.ntiles), dim3(W * 64), 0, st,
+  auto k = rb_stream(g, sizeof(T)) ? mg::rb_leg_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 2, SM, W, RPT>
+                                   : mg::rb_leg_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM, W, RPT>;
+  hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                      (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c, (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
                      (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
   return 0;
@@ -486,7 +500,9 @@ void launch_sweeps_rb_s(const void* u, const void* rhs, void* out, const LegGeom
   constexpr int HALO = 2 * mg::sweep_halo(SM);
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
-  hipLaunchKernelGGL((mg::rb_leg_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM, W, RPT>), dim3(a.ntiles), dim3(W * 64), 0, st,
+  auto k = rb_stream(g, sizeof(T)) ? mg::rb_leg_kernel<T, HALO, false, mg::kPostNone, false, T, T, 2, SM, W, RPT>
+                                   : mg::rb_leg_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM, W, RPT>;
+  hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                      (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr, (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
                      (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0);
 }
