@@ -47,9 +47,13 @@ typedef enum {
   MG_PREC_SINGLE = 1,       /* Grid(dtype=float32)                                             */
   MG_PREC_MIXED_LEVELS = 2, /* PrecisionManager('mixed'): level >= L//2 fp32 (core/precision.py:337-357) */
   MG_PREC_ADAPTIVE = 3,     /* threshold switch fp32 <-> fp64 (core/precision.py:270-302)      */
-  MG_PREC_SINGLE_MANAGED = 4/* PrecisionManager('single', adaptive=False) on a float64 Grid: every level converted to
+  MG_PREC_SINGLE_MANAGED = 4,/* PrecisionManager('single', adaptive=False) on a float64 Grid: every level converted to
                                fp32 on entry (solvers/multigrid.py:281-285) except the coarsest, which the reference never
                                converts (:270-272) and solves in fp64; interpolation in fp64 (operators/transfer.py:207) */
+  MG_PREC_DEFECT = 5        /* defect correction (iterative refinement): fp64 iterate and residual, one fp32 cycle (levels as
+                               MG_PREC_SINGLE_MANAGED) from the zero correction on A e = r per outer step, u += e in fp64.
+                               The working idea behind gpu/cuda_kernels.py:843-883,937-967 (fp32 iterate, fp64 residual) and
+                               :915-929 (correction across precisions); prec_hist code 3.  Constant coefficients only. */
 } mg_precision_t;
 
 /* Packed solver configuration: the constructor kwargs of MultigridSolver
@@ -180,6 +184,10 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
 /* ---- stateless operators on HOST arrays (upload, run the HIP kernel, download) ----------- */
 /* replaces: operators/laplacian.py:105-124 / gpu/cuda_kernels.py:794-828 (TransferKernels.compute_residual) */
 int mg_op_residual(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* u, const void* f, void* r);
+/* replaces: gpu/cuda_kernels.py:843-883, 937-967 (MixedPrecisionKernels.compute_mixed_precision_residual): fp32 iterate and
+ * rhs in, fp64 residual out, evaluated in double (16 B / DoF) -- with the operator and the boundary convention of
+ * mg_op_residual (A = coeff * Laplacian_h, r = f on boundary cells) in place of that kernel's own. */
+int mg_op_residual_mixed(int nx, int ny, double hx, double hy, double coeff, const float* u, const float* f, double* r);
 /* replaces: operators/laplacian.py:44-80 (apply = f - residual with f = 0, sign folded) */
 int mg_op_apply(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* u, void* au);
 /* replaces: core/grid.py:174-187 (Grid.l2_norm) */
@@ -211,6 +219,9 @@ int mg_dev_rbgs_colour(int dtype, int nx, int ny, int ld, double hx, double hy, 
                        int colour_offset, void* u, const void* rhs, void* stream);
 int mg_dev_residual(int dtype, int nx, int ny, int ld, double hx, double hy, double coeff,
                     const void* u, const void* f, void* r, void* stream);
+/* device form of mg_op_residual_mixed: u, f fp32 with pitch ld_in, r fp64 with pitch ld_out (elements) */
+int mg_dev_residual_f32in_f64out(int nx, int ny, int ld_in, int ld_out, double hx, double hy, double coeff, const float* u,
+                                 const float* f, double* r, void* stream);
 /* sum of squares of field[i_lo:i_hi, j_lo:j_hi] into *sumsq_dev (one double in device memory);
  * scratch >= mg_dev_scratch_bytes().  The window lets a sub-domain count the cells it owns. */
 int mg_dev_sumsq(int dtype, int ld, int i_lo, int i_hi, int j_lo, int j_hi, const void* field, void* scratch,

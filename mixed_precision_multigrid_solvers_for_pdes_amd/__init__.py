@@ -14,6 +14,7 @@ from .smoothers import (BaseSolver, ConvergenceHistory, EnhancedJacobiSolver, Ga
                         IterativeSolver, JacobiSmoother, WeightedJacobiSmoother)
 from .solver import GPUMultigridSolver, MultigridCycle, MultigridSolver
 from .engine import MultigridEngine
+from .gpu_kernels import MixedPrecisionKernels, SmoothingKernels, TransferKernels
 from .facade import MixedPrecisionMultigrid, PoissonProblem, default_max_levels
 from . import applications, heat_equation
 from .heat_equation import HeatEquationConfig, HeatEquationSolver, TimeSteppingScheme
@@ -24,6 +25,7 @@ __all__ = [
     "PrecisionLevel", "PrecisionManager", "BaseSolver", "ConvergenceHistory", "IterativeSolver",
     "JacobiSmoother", "WeightedJacobiSmoother", "EnhancedJacobiSolver", "GaussSeidelSmoother",
     "MultigridSolver", "GPUMultigridSolver", "MultigridCycle", "MultigridEngine",
+    "SmoothingKernels", "TransferKernels", "MixedPrecisionKernels",
     "MixedPrecisionMultigrid", "PoissonProblem", "default_max_levels",
     "PoissonSolver2D", "MultigridPreconditioner", "applications", "heat_equation", "HeatEquationSolver",
     "HeatEquationConfig", "TimeSteppingScheme",

@@ -12,7 +12,7 @@ MG_ERR_INVALID_VALUE, MG_ERR_NO_DEVICE, MG_ERR_HIP, MG_ERR_STATE, MG_ERR_ALLOC =
 MG_F32, MG_F64 = 0, 1
 MG_JACOBI, MG_RBGS, MG_LEXGS = 0, 1, 2
 MG_CYCLE_V, MG_CYCLE_W, MG_CYCLE_F = 0, 1, 2
-MG_PREC_DOUBLE, MG_PREC_SINGLE, MG_PREC_MIXED_LEVELS, MG_PREC_ADAPTIVE, MG_PREC_SINGLE_MANAGED = 0, 1, 2, 3, 4
+MG_PREC_DOUBLE, MG_PREC_SINGLE, MG_PREC_MIXED_LEVELS, MG_PREC_ADAPTIVE, MG_PREC_SINGLE_MANAGED, MG_PREC_DEFECT = 0, 1, 2, 3, 4, 5
 
 CYCLES = {"V": MG_CYCLE_V, "W": MG_CYCLE_W, "F": MG_CYCLE_F}
 
@@ -70,6 +70,8 @@ SIGNATURES = {
     "mg_get_stream": (_i, [_vp, C.POINTER(_vp)]),
     "mg_time_op": (_i, [_vp, _i, _i, _i, _i, _pd]),
     "mg_op_residual": (_i, [_i, _i, _i, _d, _d, _d, _vp, _vp, _vp]),
+    "mg_op_residual_mixed": (_i, [_i, _i, _d, _d, _d, _vp, _vp, _vp]),
+    "mg_dev_residual_f32in_f64out": (_i, [_i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "mg_op_apply": (_i, [_i, _i, _i, _d, _d, _d, _vp, _vp]),
     "mg_op_norm": (_i, [_i, _i, _i, _d, _d, _vp, _pd]),
     "mg_op_jacobi": (_i, [_i, _i, _i, _d, _d, _d, _i, _vp, _vp, _vp]),

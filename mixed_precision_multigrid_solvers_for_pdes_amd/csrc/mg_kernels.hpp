@@ -334,6 +334,61 @@ __global__ __launch_bounds__(kBlock) void residual_kernel(const T* __restrict__ 
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// Residual across precisions: r (TR) = f (TF) - A (u (TU) [+ e (float)]), evaluated in double.
+//   (a) TU = TF = float, TR = double: the reference's MixedPrecisionKernels.compute_mixed_precision_residual
+//       (gpu/cuda_kernels.py:843-883, 937-967: fp32 iterate and rhs in, fp64 residual out, 16 B / DoF) with the oracle's
+//       operator and boundary convention (A = coeff * Laplacian, r = f on boundary cells) instead of that kernel's
+//       inconsistent ones;
+//   (b) TU = TF = double, TR = float, UPDATE: one outer step of defect correction (MG_PREC_DEFECT): u' = u + e is formed
+//       on the fly (written to `u_out`), r = f - A u' becomes the fp32 right-hand side of the next error equation
+//       (ZERO_RING: 0 on boundary cells -- the Dirichlet data of u are exact, the error vanishes there) and
+//       sum r^2 (boundary cells: f^2, the reference's norm, operators/laplacian.py:117-118) goes to `partials`.
+//   Each thread produces two adjacent cells of one row; neighbours come straight from L1 / L2 (a side path: one pass
+//   per outer iteration, not a smoother).
+// --------------------------------------------------------------------------------------------
+template <typename TU, typename TF, typename TR, bool UPDATE, bool ZERO_RING, bool NORM>
+__global__ __launch_bounds__(kBlock) void residual_xprec_kernel(const TU* __restrict__ u, const float* __restrict__ e,
+                                                                const TF* __restrict__ f, TR* __restrict__ r,
+                                                                double* __restrict__ u_out, double* __restrict__ partials, int nx,
+                                                                int ny, int ldu, int lde, int ldf, int ldr, double ihx2, double ihy2,
+                                                                double diag, double coeff) {
+  __shared__ double red[kBlock / 64];
+  const int pairs = (ny + 1) / 2;
+  const long long total = (long long)nx * pairs;
+  double acc = 0.0;
+  auto val = [&](int i, int j) -> double {
+    double x = (double)u[(size_t)i * ldu + j];
+    if (UPDATE) x += (double)e[(size_t)i * lde + j];
+    return x;
+  };
+  for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
+    const int i = (int)(v / pairs), j0 = (int)(v - (long long)i * pairs) * 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = j0 + q;
+      if (j >= ny) continue;
+      const double fv = (double)f[(size_t)i * ldf + j];
+      const double c = val(i, j);
+      double rv;
+      if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1) {
+        const double au = coeff * (((val(i + 1, j) + val(i - 1, j)) * ihx2 + (val(i, j + 1) + val(i, j - 1)) * ihy2) - c * diag);
+        rv = fv - au;
+        r[(size_t)i * ldr + j] = (TR)rv;
+      } else {
+        rv = fv;
+        r[(size_t)i * ldr + j] = ZERO_RING ? TR(0) : (TR)fv;
+      }
+      if (UPDATE) u_out[(size_t)i * ldu + j] = c;
+      if (NORM) acc += rv * rv;
+    }
+  }
+  if (NORM) {
+    const double t = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
 // Sum of squares of field[i_lo:i_hi, j_lo:j_hi] (reference: core/grid.py:187 without the hx*hy factor and
 // sqrt).  The window lets a sub-domain count exactly the cells it owns (plus its physical boundary).
 template <typename T>

@@ -684,6 +684,7 @@ struct mg_handle {
     switch (cfg.precision) {
       case MG_PREC_SINGLE: return MG_F32;
       case MG_PREC_SINGLE_MANAGED: return MG_F32;
+      case MG_PREC_DEFECT: return MG_F32;          // the error equation's hierarchy; the iterate itself is fp64 (iterate_dtype)
       case MG_PREC_MIXED_LEVELS: return (l >= (cfg.mixed_split > 0 ? cfg.mixed_split : L() / 2)) ? MG_F32 : MG_F64;
       case MG_PREC_ADAPTIVE: return ph;
       default: return MG_F64;
@@ -693,8 +694,11 @@ struct mg_handle {
   bool fused() const { return cfg.fused != 0 && (cfg.smoother == MG_JACOBI || cfg.smoother == MG_RBGS); }
   bool needs(int l, int dt) const {
     if (cfg.precision == MG_PREC_ADAPTIVE) return (l == L() - 1) ? dt == grid_dtype : true;
+    if (cfg.precision == MG_PREC_DEFECT && l == 0 && dt == MG_F64) return true;      // fp64 iterate, its ping-pong partner and f
     return level_dtype(l) == dt;
   }
+  // precision of the fine iterate the caller sets / gets: the level-0 working precision, except for defect correction
+  int iterate_dtype() const { return cfg.precision == MG_PREC_DEFECT ? MG_F64 : level_dtype(0); }
 };
 
 namespace {
@@ -965,7 +969,7 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   }
   if (part != kPartFront) {
     StageTimer tm(h, &f, 2);
-    const bool want_norm = fine && h->cfg.post <= 2;
+    const bool want_norm = fine && h->cfg.post <= 2 && h->cfg.precision != MG_PREC_DEFECT;   // defect correction: the norm is the fp64 defect's
     g.nsweep = std::min(2, h->cfg.post);
     const int n = d_up(sm, dt, dc, h->grid_dtype, f.u[dt], f.rhs[dt], f.t[dt], c.u[dc], h->partials, g, want_norm, h->stream);
     if (n < 0) return MG_ERR_INVALID_VALUE;
@@ -1032,8 +1036,55 @@ int fmg_init(mg_handle* h, int ncyc) {
   return MG_OK;
 }
 
+void inject_rings_fwd(mg_handle* h);      // = inject_rings(h, h->phase), defined below
+
+// ---- defect correction (MG_PREC_DEFECT): fp64 iterate and residual, fp32 cycles on the error equation -----------------
+// One pass over the fine grid per outer step: u <- u + e (the fp32 correction of the cycle just run), r = f - A u in
+// fp64, stored as the fp32 right-hand side of the next error equation (zero on boundary cells), sum r^2 for the norm.
+// Returns the number of partials.
+int launch_defect(mg_handle* h, bool update) {
+  Level& v = h->lv[0];
+  const Coef c = coefs(v.hx, v.hy, h->sigma);
+  const long long pairs = (long long)v.nx * ((v.ny + 1) / 2);
+  const int nb = std::min(grid_for(pairs), 2048);
+  if (update) {
+    hipLaunchKernelGGL((mg::residual_xprec_kernel<double, double, float, true, true, true>), dim3(nb), dim3(mg::kBlock), 0, h->stream,
+                       (const double*)v.u[MG_F64], (const float*)v.u[MG_F32], (const double*)v.rhs[MG_F64], (float*)v.rhs[MG_F32],
+                       (double*)v.t[MG_F64], h->partials, v.nx, v.ny, v.ld[MG_F64], v.ld[MG_F32], v.ld[MG_F64], v.ld[MG_F32], c.ihx2,
+                       c.ihy2, c.diag, h->cfg.coeff);
+    std::swap(v.u[MG_F64], v.t[MG_F64]);
+  } else {
+    hipLaunchKernelGGL((mg::residual_xprec_kernel<double, double, float, false, true, true>), dim3(nb), dim3(mg::kBlock), 0, h->stream,
+                       (const double*)v.u[MG_F64], (const float*)nullptr, (const double*)v.rhs[MG_F64], (float*)v.rhs[MG_F32],
+                       (double*)nullptr, h->partials, v.nx, v.ny, v.ld[MG_F64], v.ld[MG_F32], v.ld[MG_F64], v.ld[MG_F32], c.ihx2,
+                       c.ihy2, c.diag, h->cfg.coeff);
+  }
+  return nb;
+}
+
+// one fp32 cycle from the zero correction on the current defect (left in lv[0].u[fp32])
+int defect_cycle(mg_handle* h) {
+  h->norm_partials = 0;
+  if (h->L() == 1) {                     // a single level: the "cycle" is the coarsest solve, in the grid dtype (fp64)
+    return MG_ERR_INVALID_VALUE;
+  }
+  if (h->fused()) return cycle_fused(h, 0, true);
+  Level& v = h->lv[0];
+  (void)hipMemsetAsync(v.u[MG_F32], 0, (size_t)v.nx * v.ld[MG_F32] * 4, h->stream);
+  return cycle(h, 0);
+}
+
 int run_cycle(mg_handle* h) {
   h->norm_partials = 0;
+  if (h->cfg.precision == MG_PREC_DEFECT) {            // one outer step: defect, fp32 cycle, update
+    if (h->varcoef) return MG_ERR_INVALID_VALUE;
+    (void)launch_defect(h, false);
+    inject_rings_fwd(h);
+    const int rc = defect_cycle(h);
+    if (rc != MG_OK) return rc;
+    (void)launch_defect(h, true);
+    return MG_OK;
+  }
   if (h->fused() && h->L() > 1) return cycle_fused(h, 0, false);
   return cycle(h, 0);
 }
@@ -1091,6 +1142,15 @@ int reduce_to_host(mg_handle* h, int n, double* value) {
 
 int fine_norm(mg_handle* h, double* out) {
   Level& v = h->lv[0];
+  if (h->cfg.precision == MG_PREC_DEFECT) {       // ||f - A u|| of the fp64 iterate (the fp32 rhs is rewritten with the same defect)
+    if (h->varcoef) return fail(&h->err, MG_ERR_INVALID_VALUE, "defect correction runs the constant-coefficient operator");
+    const int n = launch_defect(h, false);
+    double ss = 0;
+    const int rc = reduce_to_host(h, n, &ss);
+    if (rc != MG_OK) return rc;
+    *out = std::sqrt(v.hx * v.hy * ss);
+    return MG_OK;
+  }
   const int dt = h->level_dtype(0);
   if (h->norm_partials > 0 && h->ring_sumsq[dt] >= 0) {   // the up leg of the last cycle already summed r^2 over the interior cells
     double ss = 0;
@@ -1185,6 +1245,8 @@ void inject_rings(mg_handle* h, int ph) {
   }
 }
 
+void inject_rings_fwd(mg_handle* h) { inject_rings(h, h->phase); }
+
 // sum of f^2 over the boundary ring of the fine rhs (4 windows of the device reduction), per allocated dtype
 int ring_sums(mg_handle* h) {
   Level& v = h->lv[0];
@@ -1222,7 +1284,7 @@ int set_rhs_impl(mg_handle* h, const void* rhs, int hdt) {
 
 int set_u_impl(mg_handle* h, const void* u0, int hdt) {
   Level& v = h->lv[0];
-  const int dt = h->level_dtype(0);
+  const int dt = h->iterate_dtype();
   h->norm_partials = 0;
   if (u0) {
     int rc = upload(&h->err, v.u[dt], dt, v.ld[dt], u0, hdt, v.nx, v.ny, h->staging, h->stream);
@@ -1269,7 +1331,7 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
     return fail(nullptr, MG_ERR_INVALID_VALUE, "Grid must have at least 3 points in each direction");   // core/grid.py:34-35
   if (cfg->cycle < MG_CYCLE_V || cfg->cycle > MG_CYCLE_F) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown cycle type");
   if (cfg->smoother < MG_JACOBI || cfg->smoother > MG_LEXGS) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown smoother");
-  if (cfg->precision < MG_PREC_DOUBLE || cfg->precision > MG_PREC_SINGLE_MANAGED) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown precision policy");
+  if (cfg->precision < MG_PREC_DOUBLE || cfg->precision > MG_PREC_DEFECT) return fail(nullptr, MG_ERR_INVALID_VALUE, "unknown precision policy");
   if (cfg->pre < 0 || cfg->post < 0 || cfg->max_levels < 1 || cfg->coarse_maxit < 1)
     return fail(nullptr, MG_ERR_INVALID_VALUE, "negative sweep count / max_levels < 1 / coarse_maxit < 1");
   if (!(cfg->x1 > cfg->x0) || !(cfg->y1 > cfg->y0)) return fail(nullptr, MG_ERR_INVALID_VALUE, "empty domain");
@@ -1311,9 +1373,10 @@ int mg_create(const mg_config* cfg, mg_handle** out) {
       const size_t bytes = (size_t)v.nx * v.ld[dt] * esize(dt);
       if ((rc = alloc_zero(&h->err, &v.u[dt], bytes, h->stream)) != MG_OK) return bail(rc);
       if ((rc = alloc_zero(&h->err, &v.rhs[dt], bytes, h->stream)) != MG_OK) return bail(rc);
-      if (l < h->L() - 1) {
-        if ((rc = alloc_zero(&h->err, &v.r[dt], bytes, h->stream)) != MG_OK) return bail(rc);
-        if ((cfg->smoother == MG_JACOBI || h->fused()) && (rc = alloc_zero(&h->err, &v.t[dt], bytes, h->stream)) != MG_OK) return bail(rc);
+      const bool master = cfg->precision == MG_PREC_DEFECT && l == 0 && dt == MG_F64;     // iterate + partner + f only
+      if (l < h->L() - 1 || master) {
+        if (!master && (rc = alloc_zero(&h->err, &v.r[dt], bytes, h->stream)) != MG_OK) return bail(rc);
+        if ((master || cfg->smoother == MG_JACOBI || h->fused()) && (rc = alloc_zero(&h->err, &v.t[dt], bytes, h->stream)) != MG_OK) return bail(rc);
       }
     }
   }
@@ -1397,7 +1460,7 @@ int mg_zero_solution_device(mg_handle* h) {
   HIPC(&h->err, hipSetDevice(h->cfg.device));
   h->norm_partials = 0;
   Level& v = h->lv[0];
-  const int dt = h->level_dtype(0);
+  const int dt = h->iterate_dtype();
   HIPC(&h->err, hipMemsetAsync(v.u[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
   if (v.t[dt]) HIPC(&h->err, hipMemsetAsync(v.t[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
   return MG_OK;
@@ -1407,7 +1470,7 @@ int mg_get_solution_device(mg_handle* h, void* u_dev, int ld, int dtype) {
   if (!h || !u_dev || !valid_dtype(dtype) || ld < h->lv[0].ny) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_get_solution_device: bad argument");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
   Level& v = h->lv[0];
-  const int dt = h->level_dtype(0);
+  const int dt = h->iterate_dtype();
   d_convert(dt, dtype, v.u[dt], u_dev, v.nx, v.ny, v.ld[dt], ld, h->stream);
   HIPC(&h->err, hipGetLastError());
   return MG_OK;
@@ -1481,7 +1544,7 @@ int mg_get_solution(mg_handle* h, void* u_out, int host_dtype) {
   if (!h || !u_out || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_get_solution: bad argument");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
   Level& v = h->lv[0];
-  const int dt = h->level_dtype(0);
+  const int dt = h->iterate_dtype();
   return download(&h->err, u_out, host_dtype, v.u[dt], dt, v.ld[dt], v.nx, v.ny, h->staging, h->stream);
 }
 
@@ -1536,6 +1599,31 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
   if (rc != MG_OK) return rc;
   st->initial_residual = rn;
   int it = 0, conv = 0, switches = 0;
+  if (h->cfg.precision == MG_PREC_DEFECT) {
+    // outer loop of defect correction: fine_norm above left the defect of the initial iterate in the fp32 rhs; each step
+    // runs one fp32 cycle from zero on it, then ONE pass that updates the fp64 iterate, forms the next defect and its norm
+    if (h->L() < 2) return fail(&h->err, MG_ERR_INVALID_VALUE, "defect correction needs at least two levels");
+    inject_rings(h, h->phase);                      // zero rings of every coarse rhs (the error vanishes on the boundary)
+    for (it = 1; it <= max_iter; ++it) {
+      if ((rc = defect_cycle(h)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+      const int n = launch_defect(h, true);
+      double ss = 0;
+      if ((rc = reduce_to_host(h, n, &ss)) != MG_OK) return rc;
+      rn = std::sqrt(h->lv[0].hx * h->lv[0].hy * ss);
+      if (it <= hist_cap) hist[it - 1] = rn;
+      if (prec_hist && it <= hist_cap) prec_hist[it - 1] = 3;
+      if (rn < tol) { conv = 1; break; }
+    }
+    if (it > max_iter) it = max_iter;
+    HIPC(&h->err, hipMemcpyAsync(h->h_int, h->d_int, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPC(&h->err, hipStreamSynchronize(h->stream));
+    st->last_coarse_sweeps = *h->h_int;
+    st->solve_seconds = now_s() - t0;
+    st->precision_switches = 0;
+    if (n_iter) *n_iter = it;
+    if (converged) *converged = conv;
+    return MG_OK;
+  }
   // Speculative launching: while the norm of cycle `it` travels to the host, the FRONT part of cycle it+1 (level-0
   // down leg and everything below it) is already queued -- it never touches the buffer holding the iterate of
   // cycle `it`.  If that norm ends the solve or changes the working precision, the front part is simply dropped
@@ -1637,7 +1725,7 @@ int mg_solve(mg_handle* h, const void* rhs, const void* u0, void* u_out, int hos
   if (rc != MG_OK) return rc;
   t0 = now_s();
   Level& v = h->lv[0];
-  const int dt = h->level_dtype(0);
+  const int dt = h->iterate_dtype();
   rc = download(&h->err, u_out, host_dtype, v.u[dt], dt, v.ld[dt], v.nx, v.ny, h->staging, h->stream);
   if (rc != MG_OK) return rc;
   st.d2h_seconds = now_s() - t0;
@@ -1749,6 +1837,19 @@ int mg_dev_residual(int dtype, int nx, int ny, int ld, double hx, double hy, dou
   CHECK_DEV(valid_dtype(dtype) && nx >= 3 && ny >= 3 && ld_ok(dtype, ny, ld), "mg_dev_residual: bad shape / pitch");
   CHECK_DEV(u && f && r && aligned16(u) && aligned16(f) && aligned16(r), "mg_dev_residual: bad pointer");
   d_residual(dtype, u, f, r, nx, ny, ld, hx, hy, coeff, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_residual_f32in_f64out(int nx, int ny, int ld_in, int ld_out, double hx, double hy, double coeff, const float* u,
+                                 const float* f, double* r, void* stream) {
+  CHECK_DEV(nx >= 3 && ny >= 3 && ld_in >= ny && ld_out >= ny, "mg_dev_residual_f32in_f64out: bad shape / pitch");
+  CHECK_DEV(u && f && r, "mg_dev_residual_f32in_f64out: bad pointer");
+  const Coef c = coefs(hx, hy);
+  const long long pairs = (long long)nx * ((ny + 1) / 2);
+  hipLaunchKernelGGL((mg::residual_xprec_kernel<float, float, double, false, false, false>), dim3(grid_for(pairs)), dim3(mg::kBlock), 0,
+                     (hipStream_t)stream, u, (const float*)nullptr, f, r, (double*)nullptr, (double*)nullptr, nx, ny, ld_in, ld_in, ld_in,
+                     ld_out, c.ihx2, c.ihy2, c.diag, coeff);
   HIPC(nullptr, hipGetLastError());
   return MG_OK;
 }
@@ -1905,6 +2006,18 @@ int mg_op_residual(int dtype, int nx, int ny, double hx, double hy, double coeff
   RC(up(du, dtype, u, nx, ny)); RC(up(df, dtype, f, nx, ny));
   d_residual(dtype, du, df, dr, nx, ny, pitch_elems(dtype, ny), hx, hy, coeff, nullptr);
   return down(r, dtype, dr, nx, ny);
+}
+
+int mg_op_residual_mixed(int nx, int ny, double hx, double hy, double coeff, const float* u, const float* f, double* r) {
+  CHECK_DEV(u && f && r, "mg_op_residual_mixed: bad argument");
+  CHECK_DEV(nx >= 3 && ny >= 3, "Cannot apply Laplacian to grid");   // operators/laplacian.py:55-56
+  RC(need_device());
+  Scratch s; void *du, *df, *dr;
+  RC(s.get(&du, MG_F32, nx, ny)); RC(s.get(&df, MG_F32, nx, ny)); RC(s.get(&dr, MG_F64, nx, ny));
+  RC(up(du, MG_F32, u, nx, ny)); RC(up(df, MG_F32, f, nx, ny));
+  RC(mg_dev_residual_f32in_f64out(nx, ny, pitch_elems(MG_F32, ny), pitch_elems(MG_F64, ny), hx, hy, coeff, (const float*)du, (const float*)df,
+                                  (double*)dr, nullptr));
+  return down(r, MG_F64, dr, nx, ny);
 }
 
 int mg_op_apply(int dtype, int nx, int ny, double hx, double hy, double coeff, const void* u, void* au) {

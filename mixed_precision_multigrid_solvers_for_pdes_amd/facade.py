@@ -105,7 +105,7 @@ def _load_reference():
 
 
 class MixedPrecisionMultigrid:
-    STRATEGIES = ("double", "single", "mixed", "adaptive", "adaptive_reference")
+    STRATEGIES = ("double", "single", "mixed", "adaptive", "adaptive_reference", "defect")
 
     def __init__(self, precision_strategy="adaptive", switch_threshold=1e-6, use_gpu=True, max_levels=None,
                  max_iterations=50, tolerance=1e-8, cycle_type="V", pre_smooth_iterations=2,
@@ -142,6 +142,10 @@ class MixedPrecisionMultigrid:
             return None                                  # Grid(dtype=float32)
         if s == "mixed":
             return cls(default_precision="mixed", convergence_threshold=self.switch_threshold)
+        if s == "defect":          # defect correction: fp64 iterate / residual, fp32 cycles on the error equation (ours, GPU only)
+            pm = cls(default_precision="double", adaptive=False, convergence_threshold=self.switch_threshold)
+            pm.defect_correction = True
+            return pm
         pm = cls(default_precision="double", adaptive=True, convergence_threshold=self.switch_threshold)
         pm.reference_rule = (s == "adaptive_reference")
         return pm
@@ -173,6 +177,8 @@ class MixedPrecisionMultigrid:
             finally:
                 solver.cleanup()
         else:
+            if self.precision_strategy == "defect":
+                raise NotImplementedError("defect correction is a device policy (mg_config.precision = MG_PREC_DEFECT); use_gpu=True")
             mod = _load_reference()
             grid = mod.core.grid.Grid(problem.nx, problem.ny, problem.domain, dtype)
             op = mod.operators.laplacian.LaplacianOperator(coefficient=-1.0)

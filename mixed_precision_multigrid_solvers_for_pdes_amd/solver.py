@@ -29,6 +29,9 @@ def _precision_config(grid, pm):
     if pm is None:
         return _lib.MG_PREC_DOUBLE, 1e-6, 4.0, False
     thr, mem = pm.convergence_threshold, pm.memory_threshold_gb
+    if getattr(pm, "defect_correction", False):
+        # fp64 iterate and residual, fp32 cycles on the error equation (mg_config.precision = MG_PREC_DEFECT)
+        return _lib.MG_PREC_DEFECT, thr, mem, False
     if pm.current_precision == PrecisionLevel.MIXED:
         # non-adaptive 'mixed' resolves to get_dtype(MIXED) = float64 on every level (precision.py:348-349)
         return (_lib.MG_PREC_MIXED_LEVELS if pm.adaptive else _lib.MG_PREC_DOUBLE), thr, mem, False
@@ -146,7 +149,7 @@ class MultigridSolver(BaseSolver):
         u, r = eng.solve(rhs, initial_guess, self.tolerance, self.max_iterations, out_dtype=work_dtype)
         wall = time.time() - t0
         n = r["iterations"]
-        names = {0: "float32", 1: "float64", 2: "mixed"}
+        names = {0: "float32", 1: "float64", 2: "mixed", 3: "defect"}
         per_it = r["solve_seconds"] / max(n, 1)
         for k in range(n):
             level = names[r["precision_codes"][k]] if pm is not None else "double"

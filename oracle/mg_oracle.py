@@ -382,6 +382,44 @@ class MGOracle:
 
 
 # --------------------------------------------------------------------------
+# Mixed-precision residual and defect correction (gpu/cuda_kernels.py:843-883, 915-929, 937-967 are the reference's
+# building blocks: fp32 iterate / rhs in, fp64 residual out; a correction applied across precisions).  The reference
+# never assembles them into a working solver (its kernels carry the sign errors of SURVEY F5), so the LOOP below is
+# our design ("parity unpinned"); every operator inside it is one of the pinned restatements above.
+# --------------------------------------------------------------------------
+
+def residual_mixed(u32, f32, hx, hy, coeff=-1.0):
+    """fp64 residual of an fp32 iterate and rhs: operands up-cast, then `residual` (boundary r = f)."""
+    return residual(np.asarray(u32, dtype=np.float32).astype(np.float64), np.asarray(f32, dtype=np.float32).astype(np.float64),
+                    hx, hy, coeff)
+
+
+def defect_correction(mgo, rhs, u0=None, tol=1e-8, max_iterations=50):
+    """Iterative refinement around an MGOracle built on a float64 grid: fp64 iterate and residual, one cycle of `mgo`
+    under PrecisionManager('single', adaptive=False) (every level but the coarsest in fp32) from the zero correction on
+    A e = r per outer step, u += e in fp64.  The fp32 right-hand side carries a zero boundary ring (the Dirichlet
+    data of u are exact); the recorded norm is the reference's (boundary cells r = f)."""
+    pm = OraclePrecision("single", adaptive=False)
+    hx, hy = mgo.h[0]
+    u = np.zeros_like(rhs) if u0 is None else u0.astype(np.float64).copy()
+    hist = []
+    r = residual(u, rhs, hx, hy, mgo.coeff, mgo.shift)
+    r0 = float(l2_norm(r, hx, hy))
+    for _ in range(max_iterations):
+        r32 = r.astype(np.float32)
+        r32[0, :] = r32[-1, :] = 0.0
+        r32[:, 0] = r32[:, -1] = 0.0
+        mgo.rhs[0] = r32
+        e = mgo.cycle_once(np.zeros_like(rhs), 0, pm)
+        u = u + e.astype(np.float64)
+        r = residual(u, rhs, hx, hy, mgo.coeff, mgo.shift)
+        hist.append(float(l2_norm(r, hx, hy)))
+        if hist[-1] < tol:
+            break
+    return u, {"initial_residual": r0, "residual_history": hist, "iterations": len(hist), "converged": hist[-1] < tol}
+
+
+# --------------------------------------------------------------------------
 # Variable-coefficient operator  A u = coeff * div(a grad u)  -- NOT in the reference (SURVEY.md F12; README
 # bullet only).  PARITY UNPINNED: this is a restatement of OUR discretisation (csrc/mg_kernels.hpp varcoef_kernel),
 # checked by (i) a == 1 reproducing the constant-coefficient functions above bit for bit on dyadic grids and
