@@ -216,6 +216,8 @@ def main():
             "jacobi_sweep": dict(leg("jacobi", dtype, w, 3.0, 3.0), working_set_mib=ws,
                                  served_from="Infinity Cache (MALL)" if ws < 256 else "HBM"),
             "jacobi_sweep_hbm": dict(leg("jacobi_hbm", dtype, w, 3.0, 3.0), served_from="HBM (rotating sets > 768 MiB)"),
+            # the same traffic with no stencil at all (c = a + b over the same rotating sets): the memory system's ceiling
+            "stream_hbm": dict(leg("stream_hbm", dtype, w, 3.0, 3.0), served_from="HBM (rotating sets > 768 MiB)"),
             "jacobi_2sweeps": leg("sweeps2", dtype, w, 3.0, 6.0),                    # fused_jacobi_kernel<T,2,false,0,..>
             "down_leg": leg("down_leg", dtype, w, 3.25, 2 * 3.0 + 2.25),             # 2 sweeps + residual + restriction
             "up_leg": leg("up_leg", dtype, w, 3.25, 2.25 + 2 * 3.0 + 2.0),           # prolong-add + 2 sweeps + norm
@@ -237,7 +239,7 @@ def main():
         except Exception:
             traffic = None
     roof = {"bound": "hbm",
-            "kernel": f"fused_jacobi_kernel {dom_k} {dom_p} at {n}^2 (level 0): the largest time share of the timed region",
+            "kernel": f"rb_leg_kernel {dom_k} {dom_p} at {n}^2 (level 0, register-blocked fused leg): the largest time share of the timed region",
             "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
             "traffic_source": traffic_source,
             "launch_ms": dom["launch_ms"], "bytes_per_launch": dom["bytes_per_launch"],
@@ -245,7 +247,13 @@ def main():
             "unfused_equivalent_bytes": dom["unfused_equivalent_bytes"], "unfused_equivalent_gbs": dom["unfused_equivalent_gbs"],
             "smoother_hbm": {"kernel": f"jacobi_kernel f32 at {n}^2, operands rotating through > 768 MiB (HBM proper)",
                              "achieved": kern["f32"]["jacobi_sweep_hbm"]["achieved"], "frac": kern["f32"]["jacobi_sweep_hbm"]["frac"],
-                             "target_frac": 0.70},
+                             "target_frac": 0.70,
+                             "stream_ceiling_gbs": kern["f32"]["stream_hbm"]["achieved"],
+                             "frac_of_stream_ceiling": kern["f32"]["jacobi_sweep_hbm"]["achieved"] / kern["f32"]["stream_hbm"]["achieved"],
+                             "infinity_cache_resident_frac": kern["f32"]["jacobi_sweep"]["frac"],
+                             "note": "stream_ceiling = a stencil-free c = a + b kernel over the same rotating buffers, timed in this "
+                                     "run: what the memory system delivers for 2 reads + 1 write of this size; the sweep runs "
+                                     "at frac_of_stream_ceiling of it"},
             "note": "achieved = bytes the launch must move (3.25 words/DoF for a fused leg, 3 for a sweep) / hipEvent-timed "
                     "launch time; unfused_equivalent_* prices the same work as one launch per operator (SURVEY 8d) and may "
                     "exceed the HBM peak",

@@ -89,6 +89,11 @@ typedef struct mg_config {
                                 cycles per level (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:583-652) */
   int32_t speculate;         /* with fused = 1 -- 1: mg_iterate / mg_solve queue the down leg of cycle k+1 while ||r_k||
                                 travels to the host (dropped if that norm ends the solve); 0: strictly one cycle at a time */
+  int32_t coarse_direct;     /* 1 (with fused and tail, a 5 x 5 coarsest grid): the nine-unknown coarsest system is solved
+                                directly (u = A^-1 f, the inverse formed on the host) instead of by the reference's Gauss-Seidel
+                                iteration to coarse_tol (solvers/multigrid.py:119-124, 355-370).  NOT bit-identical to the
+                                reference: the two differ by at most ||A_c^-1|| coarse_tol / h_c ~ 2e-13 per coarsest visit (the
+                                error the iteration is allowed to leave); off by default, a W-cycle speed option */
   int32_t mixed_split;       /* MG_PREC_MIXED_LEVELS: first fp32 level; <= 0: num_levels / 2 (core/precision.py:351-357).
                                 Set by a caller whose handle is the lower part of a longer hierarchy (distributed.py: the
                                 replicated coarse levels below the decomposed ones keep the GLOBAL split) */
@@ -177,7 +182,8 @@ int mg_get_stream(mg_handle* h, void** stream);
  * 2 residual (store r), 3 residual+norm (no store), 4 restrict, 5 prolong+add, 6 whole cycle,
  * 7 fused down leg (2 sweeps + residual + restriction), 8 fused up leg (prolongation + 2 sweeps [+ norm on level 0]),
  * 9 two fused sweeps, 10 the op-0 Jacobi sweep rotating over >= 3 independent {u, rhs, out} sets of > 768 MiB in total
- * (allocated for the call), so that no launch finds its operands in the 256 MiB Infinity Cache: the HBM-proper figure.
+ * (allocated for the call), so that no launch finds its operands in the 256 MiB Infinity Cache: the HBM-proper figure;
+ * 11 a bare c = a + b stream over the same rotating sets (the memory system's ceiling for the sweep's 2-read + 1-write shape).
  * dtype selects the precision of `level`'s arrays (must be allocated under cfg.precision). */
 int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg_ms);
 

@@ -30,7 +30,8 @@ class MgConfig(C.Structure):
         ("switch_threshold", C.c_double), ("memory_threshold_gb", C.c_double),
         ("adaptive_reference_rule", C.c_int32),
         ("device", C.c_int32), ("profile", C.c_int32), ("colour_offset", C.c_int32), ("fused", C.c_int32),
-        ("tail", C.c_int32), ("fmg_cycles", C.c_int32), ("speculate", C.c_int32), ("mixed_split", C.c_int32),
+        ("tail", C.c_int32), ("fmg_cycles", C.c_int32), ("speculate", C.c_int32), ("coarse_direct", C.c_int32),
+        ("mixed_split", C.c_int32),
     ]
 
 

@@ -258,6 +258,15 @@ __device__ __forceinline__ double wave_reduce_sum(double x) {
   x += dpp_row_move<0x101>(x);      // row_shl:1
   return x;
 }
+// The same tree restricted to row 0 (lanes 0..15): exact when lanes 16..63 hold zeros -- the two cross-row steps of
+// wave_reduce_sum then add 0.0 -- so the result has the same bits.
+__device__ __forceinline__ double row0_reduce_sum(double x) {
+  x += dpp_row_move<0x108>(x);      // row_shl:8
+  x += dpp_row_move<0x104>(x);      // row_shl:4
+  x += dpp_row_move<0x102>(x);      // row_shl:2
+  x += dpp_row_move<0x101>(x);      // row_shl:1
+  return x;
+}
 // lane 0's value in every lane (v_readfirstlane: all lanes are active where this is used)
 __device__ __forceinline__ double wave_first(double x) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
@@ -575,6 +584,33 @@ __global__ __launch_bounds__(kBlock) void zero_interior_kernel(T* __restrict__ u
   }
 }
 
+// Bare 2-read + 1-write stream in the tile shape of the register-blocked legs (4 waves x 4 rows x 1 KB per workgroup, all
+// loads issued before the first store): c = a + b.  Not part of the path -- the yardstick bench.py times next to the
+// Jacobi sweep (mg_time_op op 11): what the memory system delivers for the sweep's traffic shape with no stencil at all.
+template <typename T>
+__global__ __launch_bounds__(256) void stream_triad_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ c, int nx,
+                                                           int nyv, int ld, int tiles_j) {
+  constexpr int N = VecW<T>::N, RPT = 4, W = 4;          // 16 rows x 1 KB: the fastest bare shape measured (tools/stream_pattern_bench2.hip)
+  const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = (tj * 64 + lane) * N, i0 = ti * (W * RPT) + w * RPT;
+  Pack<T> x[RPT], y[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    x[k] = zero_pack<T>(); y[k] = zero_pack<T>();
+    if (i0 + k < nx && j < nyv) { x[k] = ldg(a + (size_t)(i0 + k) * ld + j); y[k] = ldg(b + (size_t)(i0 + k) * ld + j); }
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    if (i0 + k < nx && j < nyv) {
+      Pack<T> o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) o.v[e] = x[k].v[e] + y[k].v[e];
+      stg(c + (size_t)(i0 + k) * ld + j, o);
+    }
+  }
+}
+
 // Element-wise precision switch (reference: core/precision.py:106-134 `astype`).
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(kBlock) void convert_kernel(const TIN* __restrict__ in, TOUT* __restrict__ out, int nx,
@@ -689,8 +725,11 @@ template <int CTRL> __device__ __forceinline__ float dpp_row_move(float x) {
 // cell in registers; the arithmetic is coarse_lexgs_kernel's variable-coefficient branch.
 template <typename T, bool VAR = false>
 __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf, T hx2, T hy2, T diag, T coeff, T omega,
-                                   T one_m_omega, bool exact, double hxhy, double tol, int maxit, int lane,
+                                   T one_m_omega, bool exact, double hxhy, double tol_x, int maxit, int lane,
                                    const T* __restrict__ sa = nullptr, T sigma = T(0)) {
+  // tol_x: the stop test sqrt(hx hy sum r^2) < tol as  hx hy sum r^2 < tol_x  with tol_x = min{x : sqrt(x) >= tol}
+  // (host, sqrt_threshold): the same decision for every x -- IEEE sqrt is monotone -- without the ~20 dependent
+  // instructions of a double-precision square root in every sweep of a one-wave latency chain
   constexpr int ny = 5;
   const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
   double ring = 0.0;
@@ -749,8 +788,8 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
       const T sx = VAR ? aip * dn + aim * up : dn + up, sy = VAR ? ajp * rt + ajm * lf : rt + lf;
       const T rv = fv - coeff * ((exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap * (VAR ? Dv : diag));
       double acc = mine ? (double)rv * (double)rv : 0.0;
-      acc = wave_first(wave_reduce_sum(acc));
-      if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
+      acc = wave_first(row0_reduce_sum(acc));       // nine non-zero lanes, all in row 0
+      if (hxhy * (acc + ring) < tol_x || kc >= maxit) {
         result = snap;
         sweeps = kc;
         break;
@@ -767,8 +806,8 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
 template <typename T, bool VAR = false>
 __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* __restrict__ hist, int nx, int ny,
                                T hx2, T hy2, T diag, T coeff, T omega, T one_m_omega, bool exact, double hxhy,
-                               double tol, int maxit, int lane, const T* __restrict__ sa = nullptr, T sigma = T(0)) {
-  if (nx == 5 && ny == 5) return lexgs_pipelined_5x5<T, VAR>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, exact, hxhy, tol, maxit, lane, sa, sigma);
+                               double tol_x, int maxit, int lane, const T* __restrict__ sa = nullptr, T sigma = T(0)) {
+  if (nx == 5 && ny == 5) return lexgs_pipelined_5x5<T, VAR>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, exact, hxhy, tol_x, maxit, lane, sa, sigma);
   // face means and diagonal of cell c (variable coefficient; coarse_lexgs_kernel's expressions)
   auto faces = [&](int c, T& aip, T& aim, T& ajp, T& ajm, T& Dv) {
     const T ac = sa[c];
@@ -833,7 +872,7 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
         }
         acc = wave_reduce_sum(acc);
         acc = wave_first(acc);
-        if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
+        if (hxhy * (acc + ring) < tol_x || kc >= maxit) {
           if (c < ncell) su[c] = snap[c];
           sweeps = kc;
           break;
@@ -883,7 +922,7 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
       }
       acc = wave_reduce_sum(acc);
       acc = wave_first(acc);
-      if (sqrt(hxhy * (acc + ring)) < tol || kc >= maxit) {
+      if (hxhy * (acc + ring) < tol_x || kc >= maxit) {
         for (int c = lane; c < ncell; c += 64) su[c] = snap[c];
         sweeps = kc;
         break;
@@ -902,7 +941,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ u, const T* __restrict__ rhs, int nx,
                                                                 int ny, int ld, T hx2, T hy2, T omega, T one_m_omega,
                                                                 T diag, T coeff, double hxhy, double tol, int maxit,
-                                                                int* __restrict__ sweeps_out, int zero_init, int exact_recip) {
+                                                                int* __restrict__ sweeps_out, int zero_init, int exact_recip, double tol_x) {
   // exact_recip: hx^2, hy^2 and the diagonal are powers of two, so x / c == x * (1/c) bit for bit and the
   // three IEEE divisions per cell (the reference divides, solvers/smoothers.py:165-170) become multiplications.
   const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
@@ -918,7 +957,7 @@ __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ 
   __syncthreads();
   if (nx * ny <= kPipeCells && (nx + ny - 5) / 2 + 2 <= kPipeSlots) {
     const int sw = lexgs_pipelined<T>(su, sf, hist, nx, ny, hx2, hy2, diag, coeff, omega, one_m_omega, exact_recip != 0,
-                                      hxhy, tol, maxit, lane);
+                                      hxhy, tol_x, maxit, lane);
     __syncthreads();
     for (int idx = lane; idx < nx * ny; idx += 64) {
       const int i = idx / ny, j = idx - i * ny;
@@ -1092,10 +1131,14 @@ struct TailArgs {
   int smoother;                // kSmJacobi / kSmRbgs
   int colour_offset;
   double omega, coeff, tol;
+  double tol_x;                // min{x : sqrt(x) >= tol}: the coarsest stop test without the square root (sqrt_threshold)
   double sigma;                // Helmholtz shift of the variable-coefficient diagonal (constant path: folded into diag)
   TailLevel lv[kTailMaxLevels];
   const void* a_lv[kTailMaxLevels];   // VAR: the coefficient field of every tail level in HBM (dtype of that level)
   int a_ld[kTailMaxLevels];
+  int direct;                  // 1: the 5 x 5 coarsest system (nine unknowns, zero ring) is solved by u = minv f instead of the
+                               // reference's Gauss-Seidel iteration to coarse_tol (mg_config.coarse_direct; not bit-identical)
+  double minv[81];             // inverse of the 9 x 9 coarsest matrix, row-major (host, long double elimination)
 };
 
 // variable coefficient: the relaxed value of cell idx from the vertex values `A` (varcoef_kernel's expressions)
@@ -1284,10 +1327,24 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
           for (int c = lane; c < nx * ny; c += 64) su[c] = TCO(0);
           __builtin_amdgcn_wave_barrier();
         }
-        if (nx * ny <= kPipeCells && (nx + ny - 5) / 2 + 2 <= kPipeSlots) {
+        if (a.direct && nx == 5 && ny == 5) {
+          // nine unknowns in lanes 0..8: u_i = sum_j minv[i][j] f_j, f_j broadcast from lane j; a fixed summation order
+          const int li = lane < 9 ? lane : 0;
+          const int g = (li / 3 + 1) * 5 + (li % 3) + 1;
+          const double fv = (double)sf[g];
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < 9; ++j) {
+            const double fj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fv), j), __builtin_amdgcn_readlane(__double2loint(fv), j));
+            acc += a.minv[li * 9 + j] * fj;
+          }
+          if (lane < 9) su[g] = (TCO)acc;
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0 && sweeps_out) *sweeps_out = 0;
+        } else if (nx * ny <= kPipeCells && (nx + ny - 5) / 2 + 2 <= kPipeSlots) {
           // kPipeSlots snapshots behind the last level's arrays
           const int sw = lexgs_pipelined<TCO, VAR>(Ulast, Flast, Hist, nx, ny, hx2, hy2, diag, cf, TCO(1), TCO(0), exact, L.hxhy,
-                                                   a.tol, a.maxit, lane, VAR ? Alast : nullptr, (TCO)a.sigma);
+                                                   a.tol_x, a.maxit, lane, VAR ? Alast : nullptr, (TCO)a.sigma);
           if (lane == 0 && sweeps_out) *sweeps_out = sw;
         } else {
         int it = 0;

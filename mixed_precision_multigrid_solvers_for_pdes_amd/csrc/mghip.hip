@@ -96,6 +96,20 @@ inline size_t max_partials(int nx, int ny) {
   return (size_t)std::max<long long>(2048, ti * tj);
 }
 
+// min{x >= 0 : sqrt(x) >= tol}: "sqrt(x) < tol" and "x < sqrt_threshold(tol)" decide alike for every double x (IEEE sqrt is
+// correctly rounded, hence monotone) -- lets a latency-bound stop test skip the square root.  tol <= 0 never stops.
+inline double sqrt_threshold(double tol) {
+  if (!(tol > 0.0)) return 0.0;
+  thread_local double last_tol = -1.0, last_thr = 0.0;       // one tolerance per solver in practice: launched per tail visit
+  if (tol == last_tol) return last_thr;
+  last_tol = tol;
+  double y = tol * tol;
+  while (y > 0.0 && std::sqrt(y) >= tol) y = std::nextafter(y, 0.0);
+  while (std::sqrt(y) < tol) y = std::nextafter(y, INFINITY);
+  last_thr = y;
+  return y;
+}
+
 inline int grid_for(long long work_items) {
   long long b = (work_items + mg::kBlock - 1) / mg::kBlock;
   return (int)std::max<long long>(1, std::min<long long>(b, 256 * 16));
@@ -189,7 +203,7 @@ void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, 
   if (nx * ny <= mg::kCoarseLdsCells) {
     hipLaunchKernelGGL(mg::coarse_lexgs_small_kernel<T>, dim3(1), dim3(64), 0, st, (T*)u, (const T*)rhs, nx, ny, ld,
                        (T)(hx * hx), (T)(hy * hy), (T)omega, (T)(1.0 - omega), (T)c.diag, (T)coeff, hx * hy, tol, maxit,
-                       sweeps_dev, zero_init ? 1 : 0, c.all_pow2 ? 1 : 0);
+                       sweeps_dev, zero_init ? 1 : 0, c.all_pow2 ? 1 : 0, sqrt_threshold(tol));
     return;
   }
   if (zero_init) (void)hipMemsetAsync(u, 0, (size_t)nx * ld * sizeof(T), st);
@@ -199,8 +213,11 @@ void launch_coarse(void* u, const void* rhs, int nx, int ny, int ld, double hx, 
 }
 
 // ------------------------------------------------------------------ dtype dispatch --------------
+bool jacobi_rb(int dt, const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy, double omega,
+               hipStream_t st, double sigma);       // the register-blocked single sweep (defined with the other launchers below)
 void d_jacobi(int dt, const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy,
               double omega, hipStream_t st, bool fine = false, double sigma = 0.0) {
+  if (jacobi_rb(dt, u, rhs, out, nx, ny, ld, hx, hy, omega, st, sigma)) return;
   if (dt == MG_F32) launch_jacobi<float>(u, rhs, out, nx, ny, ld, hx, hy, omega, st, fine, sigma);
   else launch_jacobi<double>(u, rhs, out, nx, ny, ld, hx, hy, omega, st, fine, sigma);
 }
@@ -528,6 +545,20 @@ void launch_sweeps_rb(const void* u, const void* rhs, void* out, const LegGeom& 
   MG_RB_DISPATCH((launch_sweeps_rb_s<T, SM, 4, 8>(u, rhs, out, g, st)), (launch_sweeps_rb_s<T, SM, 8, 8>(u, rhs, out, g, st)))
 }
 
+// One weighted-Jacobi sweep on a level above ~1100^2 cells: the register-blocked sweeps kernel with nsweep = 1 (same
+// arithmetic, same ping-pong contract as jacobi_kernel: interior rows written, the ring of `out` already equals u's).
+// MG_JACOBI_RB=0 keeps the LDS-tiled jacobi_kernel (A/B runs).
+bool jacobi_rb(int dt, const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy, double omega,
+               hipStream_t st, double sigma) {
+  static const int on = [] { const char* e = std::getenv("MG_JACOBI_RB"); return e ? std::atoi(e) : 1; }();
+  LegGeom g{nx, ny, ld, 0, 0, 0, hx, hy, omega, 0.0, 1, 0, true};
+  g.sigma = sigma; g.rb = 1;
+  // only where the arrays stream from HBM (4097^2 fp64: 81 -> 78 us); Infinity-Cache-resident sweeps are faster LDS-tiled
+  if (!on || !use_rb(g, mg::kSmJacobi) || !rb_stream(g, esize(dt))) return false;
+  if (dt == MG_F32) launch_sweeps_rb<float, mg::kSmJacobi>(u, rhs, out, g, st); else launch_sweeps_rb<double, mg::kSmJacobi>(u, rhs, out, g, st);
+  return true;
+}
+
 template <int SM>
 void d_down_sm(int dt, int dx, const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
   if (use_rb(g, SM)) {
@@ -673,6 +704,9 @@ struct mg_handle {
   int tail_start = -1;             // first level of the single-workgroup LDS tail (-1: none)
   int* d_tail_ops = nullptr;       // device copy of the tail schedule
   int tail_nops = 0;
+  bool tail_direct = false;        // cfg.coarse_direct applies: 5 x 5 coarsest grid inside the tail; tail_minv is its inverse
+  double tail_minv[81] = {0};
+  double tail_minv_sigma = -1.0;   // the shift tail_minv was built for (rebuilt when mg_set_shift changes it)
   std::string err;
   std::vector<double> adapt_hist;
 
@@ -853,6 +887,7 @@ int tail_set_attr(size_t bytes) {
 // kTailMaxLevels levels and (per-level MIXED policy) one dtype on levels k .. L-2.
 int plan_tail(mg_handle* h) {
   h->tail_start = -1;
+  h->tail_direct = false;
   if (h->d_tail_ops) { (void)hipFree(h->d_tail_ops); h->d_tail_ops = nullptr; }      // re-planned when the operator changes
   const int L = h->L();
   if (!h->fused() || L < 3 || h->cfg.pre > 8 || h->cfg.post > 8) return MG_OK;
@@ -867,7 +902,10 @@ int plan_tail(mg_handle* h) {
     h->tail_start = k;
     break;
   }
+  h->tail_direct = false;
+  h->tail_minv_sigma = -1.0;
   if (h->tail_start < 0) return MG_OK;
+  h->tail_direct = h->cfg.coarse_direct != 0 && h->lv[L - 1].nx == 5 && h->lv[L - 1].ny == 5;
   std::vector<int> ops;
   tail_schedule(h, h->tail_start, h->tail_start, 2, ops);
   h->tail_nops = (int)ops.size();
@@ -879,6 +917,55 @@ int plan_tail(mg_handle* h) {
   return MG_OK;
 }
 
+// Inverse of the coarsest 5 x 5 system the smoothers relax: (-div(a grad .) + sigma) u = f on the nine interior cells,
+// zero ring (a == 1 without a coefficient field).  Gaussian elimination with partial pivoting in long double.
+int build_coarse_inverse(mg_handle* h) {
+  const Level& v = h->lv[h->L() - 1];
+  double a[25];
+  for (double& x : a) x = 1.0;
+  if (h->varcoef) {
+    const int dt = h->grid_dtype;
+    std::vector<unsigned char> buf((size_t)5 * v.ld[dt] * esize(dt));
+    HIPC(&h->err, hipMemcpyAsync(buf.data(), v.a[dt], buf.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPC(&h->err, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j)
+        a[i * 5 + j] = dt == MG_F32 ? (double)reinterpret_cast<const float*>(buf.data())[(size_t)i * v.ld[dt] + j]
+                                    : reinterpret_cast<const double*>(buf.data())[(size_t)i * v.ld[dt] + j];
+  }
+  const long double ihx2 = 1.0L / ((long double)v.hx * v.hx), ihy2 = 1.0L / ((long double)v.hy * v.hy);
+  long double M[9][18];
+  for (int p = 0; p < 9; ++p) {
+    for (int q = 0; q < 18; ++q) M[p][q] = (q == 9 + p) ? 1.0L : 0.0L;
+    const int i = p / 3 + 1, j = p % 3 + 1;
+    const long double c = a[i * 5 + j];
+    const long double aip = 0.5L * (c + a[(i + 1) * 5 + j]), aim = 0.5L * (c + a[(i - 1) * 5 + j]);
+    const long double ajp = 0.5L * (c + a[i * 5 + j + 1]), ajm = 0.5L * (c + a[i * 5 + j - 1]);
+    M[p][p] = (aip + aim) * ihx2 + (ajp + ajm) * ihy2 + (long double)h->sigma;
+    if (i < 3) M[p][p + 3] = -aip * ihx2;
+    if (i > 1) M[p][p - 3] = -aim * ihx2;
+    if (j < 3) M[p][p + 1] = -ajp * ihy2;
+    if (j > 1) M[p][p - 1] = -ajm * ihy2;
+  }
+  for (int c = 0; c < 9; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 9; ++r) if (fabsl(M[r][c]) > fabsl(M[piv][c])) piv = r;
+    if (M[piv][c] == 0.0L) return fail(&h->err, MG_ERR_INVALID_VALUE, "coarse_direct: singular coarsest system");
+    if (piv != c) for (int q = 0; q < 18; ++q) std::swap(M[piv][q], M[c][q]);
+    const long double d = 1.0L / M[c][c];
+    for (int q = 0; q < 18; ++q) M[c][q] *= d;
+    for (int r = 0; r < 9; ++r) {
+      if (r == c || M[r][c] == 0.0L) continue;
+      const long double f = M[r][c];
+      for (int q = 0; q < 18; ++q) M[r][q] -= f * M[c][q];
+    }
+  }
+  for (int p = 0; p < 9; ++p)
+    for (int q = 0; q < 9; ++q) h->tail_minv[p * 9 + q] = (double)M[p][9 + q];
+  h->tail_minv_sigma = h->sigma;
+  return MG_OK;
+}
+
 int launch_tail(mg_handle* h, bool zero_top) {
   const int k = h->tail_start, L = h->L();
   const int dt = h->level_dtype(k), dco = h->grid_dtype;
@@ -886,9 +973,15 @@ int launch_tail(mg_handle* h, bool zero_top) {
   std::memset(&a, 0, sizeof(a));
   a.nlev = L - k; a.nops = h->tail_nops; a.pre = h->cfg.pre; a.post = h->cfg.post;
   a.ld_top = h->lv[k].ld[dt]; a.maxit = h->cfg.coarse_maxit;
-  a.omega = h->cfg.omega; a.coeff = h->cfg.coeff; a.tol = h->cfg.coarse_tol;
+  a.omega = h->cfg.omega; a.coeff = h->cfg.coeff; a.tol = h->cfg.coarse_tol; a.tol_x = sqrt_threshold(h->cfg.coarse_tol);
   a.smoother = (h->cfg.smoother == MG_RBGS) ? mg::kSmRbgs : mg::kSmJacobi; a.colour_offset = h->cfg.colour_offset & 1;
   a.sigma = h->sigma;
+  a.direct = 0;
+  if (h->tail_direct) {
+    if (h->tail_minv_sigma != h->sigma) { const int rc = build_coarse_inverse(h); if (rc != MG_OK) return rc; }
+    a.direct = 1;
+    std::memcpy(a.minv, h->tail_minv, sizeof(a.minv));
+  }
   const bool var = h->varcoef;
   const size_t extra = var ? 1 : 0;
   size_t off = 0;
@@ -1516,6 +1609,7 @@ int mg_set_coefficient(mg_handle* h, const void* a_host, int host_dtype) {
   HIPC(&h->err, hipStreamSynchronize(h->stream));
   const bool was = h->varcoef;
   h->varcoef = true;
+  h->tail_minv_sigma = -1.0;                               // a direct coarsest solve needs the inverse of the NEW operator
   return was ? MG_OK : plan_tail(h);                       // the LDS tail carries one more array per level
 }
 
@@ -1750,7 +1844,7 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
   std::vector<void*> hbm_sets;
   struct FreeSets { std::vector<void*>& v; ~FreeSets() { for (void* p : v) (void)hipFree(p); } } free_sets{hbm_sets};
   int nsets = 0, set_idx = 0;
-  if (op == 10) {
+  if (op == 10 || op == 11) {
     const size_t bytes = (size_t)v.nx * v.ld[dt] * esize(dt);
     nsets = std::max<int>(3, (int)((768ull << 20) / (3 * bytes)) + 1);
     for (int k = 0; k < 3 * nsets; ++k) {
@@ -1768,6 +1862,11 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
       switch (op) {
         case 10: { void** b = hbm_sets.data() + 3 * (set_idx++ % nsets);
                    d_jacobi(dt, b[0], b[1], b[2], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, level == 0); } break;
+        case 11: { void** b = hbm_sets.data() + 3 * (set_idx++ % nsets);       // the bare stream: same traffic, no stencil
+                   const int N = (int)(16 / esize(dt)), nyv = std::min(v.ld[dt], (v.ny + N - 1) / N * N);
+                   const int tiles_j = (nyv / N + 63) / 64, tiles_i = (v.nx + 15) / 16;
+                   if (dt == MG_F32) hipLaunchKernelGGL(mg::stream_triad_kernel<float>, dim3(tiles_i * tiles_j), dim3(256), 0, h->stream, (const float*)b[0], (const float*)b[1], (float*)b[2], v.nx, nyv, v.ld[dt], tiles_j);
+                   else hipLaunchKernelGGL(mg::stream_triad_kernel<double>, dim3(tiles_i * tiles_j), dim3(256), 0, h->stream, (const double*)b[0], (const double*)b[1], (double*)b[2], v.nx, nyv, v.ld[dt], tiles_j); } break;
         case 0: d_jacobi(dt, v.u[dt], v.rhs[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, h->stream, level == 0);
                 std::swap(v.u[dt], v.t[dt]); break;
         case 1: for (int c = 0; c < 2; ++c) d_rbgs_colour(dt, v.u[dt], v.rhs[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->cfg.omega, c, h->cfg.colour_offset, h->stream, level == 0); break;

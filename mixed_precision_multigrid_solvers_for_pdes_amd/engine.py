@@ -13,7 +13,7 @@ class MultigridEngine:
                  smoother=_lib.MG_JACOBI, omega=0.8, coarse_tol=1e-12, coarse_maxit=1000,
                  precision=_lib.MG_PREC_DOUBLE, switch_threshold=1e-6, memory_threshold_gb=4.0,
                  adaptive_reference_rule=False, device=0, profile=False, colour_offset=0, fused=2, tail=True, speculate=True, fmg_cycles=0,
-                 mixed_split=0):
+                 mixed_split=0, coarse_direct=False):
         lib = _lib.load()
         # fused: 0 / False one launch per operator; 1 / True fused legs tiled through LDS; 2 (default) the same legs
         # register-blocked on levels above ~1100^2 cells; 3 register-blocked on every level (include/mghip.h mg_config.fused)
@@ -26,7 +26,7 @@ class MultigridEngine:
                             float(omega), float(coarse_tol), int(coarse_maxit), int(precision),
                             float(switch_threshold), float(memory_threshold_gb), int(bool(adaptive_reference_rule)),
                             int(device), int(bool(profile)), int(colour_offset), int(fused), int(bool(tail)), int(fmg_cycles), int(bool(speculate)),
-                            int(mixed_split))
+                            int(bool(coarse_direct)), int(mixed_split))
         self.cfg = cfg
         self._h = C.c_void_p(None)
         _lib.check(lib.mg_create(C.byref(cfg), C.byref(self._h)))
@@ -157,7 +157,7 @@ class MultigridEngine:
 
     def time_op(self, op, level=0, dtype=np.float64, reps=20):
         ops = {"jacobi": 0, "rbgs": 1, "residual": 2, "residual_norm": 3, "restrict": 4, "prolong": 5, "cycle": 6,
-               "down_leg": 7, "up_leg": 8, "sweeps2": 9, "jacobi_hbm": 10}
+               "down_leg": 7, "up_leg": 8, "sweeps2": 9, "jacobi_hbm": 10, "stream_hbm": 11}
         out = C.c_double(0.0)
         self._check(self._lib.mg_time_op(self._h, ops[op] if isinstance(op, str) else int(op), int(level),
                                          _lib.dtype_code(dtype), int(reps), C.byref(out)))

@@ -352,3 +352,28 @@ def test_config5_size_16385_mixed_w_rbgs_single_gpu():
     assert h[0] < 1e-6 and h[1] < 0.5 * h[0] and h[2] < 1.1 * h[1] and h[2] < 1e-7, h
     exact = np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
     assert np.max(np.abs(out[0][0] - exact)) < 1e-6
+
+
+@pytest.mark.parametrize("key", ["n33_L4_W_jacobi08_float64__hist", "n65_L5_W_rbgs_float64__hist", "n129_L6_W_rbgs_float64__hist",
+                                 "n65_L5_W_jacobi08_float64__hist", "n129_L6_V_vjacobi08_float64__hist"])
+def test_direct_coarsest_solve_stays_within_the_parity_bar(golden_solves, key):
+    """mg_config.coarse_direct = 1 replaces the reference's Gauss-Seidel iteration on the 5 x 5 coarsest grid (to 1e-12,
+    solvers/multigrid.py:119-124) by the exact solve of its nine unknowns.  Not bit-identical by construction -- the
+    iteration may leave an error of ||A^-1|| 1e-12 / h ~ 2e-13 per visit -- but the reference's W-cycle goldens are
+    reproduced within north_star's 1e-12 relative l-inf, with the same iteration count."""
+    m = SOLVE_RE.fullmatch(key)
+    n, L, cyc, sm = int(m.group(1)), int(m.group(4)), m.group(5), m.group(7)
+    kind, omega = (_lib.MG_RBGS, 1.0) if sm == "rbgs" else (_lib.MG_JACOBI, 0.8)
+    rhs = O.sine_rhs(n, n)
+    ref_hist, ref_u = golden_solves[key], golden_solves[key.replace("__hist", "__u")] if key.replace("__hist", "__u") in golden_solves.files else None
+    out = {}
+    for direct in (True, False):
+        eng = mg.MultigridEngine(n, n, max_levels=L, cycle=cyc, smoother=kind, omega=omega, coarse_direct=direct)
+        out[direct] = eng.solve(rhs, tol=1e-10, max_iterations=30)
+        eng.close()
+    u, r = out[True]
+    assert r["iterations"] == len(ref_hist) and r["last_coarse_sweeps"] == 0 and out[False][1]["last_coarse_sweeps"] >= 1
+    np.testing.assert_allclose(r["residual_history"], ref_hist, rtol=1e-6, atol=5e-13)
+    if ref_u is not None:
+        assert np.max(np.abs(u - ref_u)) / np.max(np.abs(ref_u)) <= 1e-12
+    assert np.max(np.abs(u - out[False][0])) / np.max(np.abs(u)) <= 1e-12 and not np.array_equal(u, out[False][0])
