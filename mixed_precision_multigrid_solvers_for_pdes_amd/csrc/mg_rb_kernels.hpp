@@ -82,12 +82,16 @@ __device__ __forceinline__ void rb_exchange(Pack<T>* __restrict__ xb, int w, int
 // stores of the output tile, bit 1 non-temporal loads of u, bit 2 of rhs.  For arrays that cannot stay in the 256 MiB
 // Infinity Cache from one leg to the next (4097^2 fp64: u, t and rhs are 3 x 136 MB) the hints keep the streamed
 // operands from evicting each other; arrays that do fit (4097^2 fp32) are faster without them.
-template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int SM, int W, int RPT, bool INT, int NT>
+// VAR: the variable-coefficient operator (varcoef_kernel's discretisation and association order): the strip of `a` is
+// loaded with u and rhs, its edge rows go through the exchange once, and the face means of the lane's cells --
+// (RPT + 1) x N vertical, RPT x (N + 1) horizontal -- live in registers for the whole leg.
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int SM, int W, int RPT, bool INT, int NT,
+          bool VAR>
 __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
                                             const TX* __restrict__ e_coarse, TX* __restrict__ rhs_coarse,
                                             double* __restrict__ partials, const FusedArgs& a, T ihx2, T ihy2, T invD, T D, T omega,
                                             T one_m_omega, T coeff, Pack<T>* __restrict__ xbuf, TX* __restrict__ patch,
-                                            double* __restrict__ red, int i0, int j0) {
+                                            double* __restrict__ red, int i0, int j0, const T* __restrict__ acoef, T sigma) {
   using S = RbShape<T, HALO, W, RPT>;
   constexpr int N = S::N;
   constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
@@ -116,6 +120,35 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
     if (INT || (gi >= 0 && gi < a.nx && col_in)) {
       F[k] = (NT & 4) ? ldg_nt(rhs + (size_t)gi * a.ld + gj0) : ldg(rhs + (size_t)gi * a.ld + gj0);
       if (!ZERO_INIT) U[k] = (NT & 2) ? ldg_nt(u + (size_t)gi * a.ld + gj0) : ldg(u + (size_t)gi * a.ld + gj0);
+    }
+  }
+  // ---- VAR: face means of the lane's cells ------------------------------------------------------------------------
+  constexpr int AVK = VAR ? RPT + 1 : 1, AHK = VAR ? RPT : 1, AHN = VAR ? N + 1 : 1;
+  Pack<T> av[AVK];            // av[k]: faces between strip rows k - 1 and k (a(i-1/2) of row k, a(i+1/2) of row k - 1)
+  T ah[AHK][AHN];             // ah[k][e]: face between the lane's cells e - 1 and e of row k (e = 0 / N: towards the neighbour lane)
+  if (VAR) {
+    Pack<T> A[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int gi = ri0 + r_base + k;
+      A[k] = zero_pack<T>();
+      if (INT || (gi >= 0 && gi < a.nx && col_in)) A[k] = ldg(acoef + (size_t)gi * a.ld + gj0);
+    }
+    Pack<T> a_above, a_below;
+    rb_exchange<T, W>(xbuf + (size_t)W * 2 * 64, w, lane, A[0], A[RPT - 1], a_above, a_below);      // buffer 1: the first sweep uses buffer 0
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const Pack<T> up = (k > 0) ? A[k > 0 ? k - 1 : 0] : a_above;
+      const Pack<T> dn = (k < RPT - 1) ? A[k < RPT - 1 ? k + 1 : 0] : a_below;
+      const T left = dpp_from_lower_lane<T>(A[k].v[N - 1]);
+      const T right = dpp_from_upper_lane<T>(A[k].v[0]);
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        av[VAR ? k : 0].v[e] = T(0.5) * (A[k].v[e] + up.v[e]);
+        if (k == RPT - 1) av[VAR ? RPT : 0].v[e] = T(0.5) * (A[k].v[e] + dn.v[e]);
+        ah[VAR ? k : 0][VAR ? e : 0] = T(0.5) * (A[k].v[e] + ((e == 0) ? left : A[k].v[e > 0 ? e - 1 : 0]));
+      }
+      ah[VAR ? k : 0][VAR ? N : 0] = T(0.5) * (A[k].v[N - 1] + right);
     }
   }
   if (PROLONG) {
@@ -186,8 +219,17 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
         for (int e = 0; e < N; ++e) {
           const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
           const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
-          const T nb = ihx2 * (dn.v[e] + prev.v[e]) + ihy2 * (ea + wv);
-          const T un = a.use_div ? (F[k].v[e] + nb) / D : (F[k].v[e] + nb) * invD;
+          T un;
+          if (VAR) {
+            const T aip = av[VAR ? k + 1 : 0].v[e], aim = av[VAR ? k : 0].v[e];
+            const T ajp = ah[VAR ? k : 0][VAR ? e + 1 : 0], ajm = ah[VAR ? k : 0][VAR ? e : 0];
+            const T sx = aip * dn.v[e] + aim * prev.v[e], sy = ajp * ea + ajm * wv;
+            const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+            un = (F[k].v[e] + (ihx2 * sx + ihy2 * sy)) / ((sigma != T(0)) ? D0 + sigma : D0);
+          } else {
+            const T nb = ihx2 * (dn.v[e] + prev.v[e]) + ihy2 * (ea + wv);
+            un = a.use_div ? (F[k].v[e] + nb) / D : (F[k].v[e] + nb) * invD;
+          }
           const T res = one_m_omega * mid.v[e] + omega * un;
           const int gj = gj0 + e;
           const bool mine = (SM != kSmRbgs) || (((par0 + k + e) & 1) == colour);
@@ -235,7 +277,16 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
         for (int e = 0; e < N; ++e) {
           const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
           const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
-          const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + wv) * ihy2) - mid.v[e] * D);
+          T au;
+          if (VAR) {
+            const T aip = av[VAR ? k + 1 : 0].v[e], aim = av[VAR ? k : 0].v[e];
+            const T ajp = ah[VAR ? k : 0][VAR ? e + 1 : 0], ajm = ah[VAR ? k : 0][VAR ? e : 0];
+            const T sx = aip * dn.v[e] + aim * up.v[e], sy = ajp * ea + ajm * wv;
+            const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+            au = coeff * ((sx * ihx2 + sy * ihy2) - mid.v[e] * ((sigma != T(0)) ? D0 + sigma : D0));
+          } else {
+            au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + wv) * ihy2) - mid.v[e] * D);
+          }
           const int gj = gj0 + e;
           if (INT || (gj >= 1 && gj < a.ny - 1)) {
             o.v[e] = F[k].v[e] - au;
@@ -283,13 +334,16 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
   }
 }
 
-template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int W, int RPT>
+template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int W, int RPT,
+          bool VAR = false>
 __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
     const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
     const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
     TX* __restrict__ rhs_coarse,          // POST == kPostRestrict: coarse rhs (dtype TX)
     double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 per block
-    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
+    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff,
+    const T* __restrict__ acoef,          // VAR: vertex values of the diffusion coefficient (shape / pitch of u)
+    T sigma) {                            // VAR: Helmholtz shift added to the per-cell diagonal
   using S = RbShape<T, HALO, W, RPT>;
   constexpr int N = S::N;
   constexpr int kNT = (TAG == 2) ? MG_RB_NT_MODE : 0;           // TAG 2: the streaming-hint variant for arrays beyond the Infinity Cache
@@ -325,11 +379,13 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
     interior = interior && ((i0 + 1) >> 1) + a.ci_off >= 1 && ((i0 + S::TI - 1) >> 1) + a.ci_off <= a.nxc - 2 &&
                (j0 >> 1) + a.cj_off >= 1 && ((j0 + S::TJ - 2) >> 1) + a.cj_off <= a.nyc - 2;
   if (interior)
-    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, true, kNT>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD,
-                                                                           D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0);
+    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, true, kNT, VAR>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2,
+                                                                                invD, D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0,
+                                                                                acoef, sigma);
   else
-    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, false, kNT>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD,
-                                                                            D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0);
+    rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, false, kNT, VAR>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2,
+                                                                                 invD, D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0,
+                                                                                 acoef, sigma);
 }
 
 }  // namespace mg

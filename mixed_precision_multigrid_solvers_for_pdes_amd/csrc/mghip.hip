@@ -449,14 +449,6 @@ void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, 
 }
 
 // ---- register-blocked legs (mg_rb_kernels.hpp): constant coefficients, levels above ~1100^2 cells ------------------
-// Workgroup shape (waves x rows per wave).  MG_RB_SHAPE selects among the compiled shapes at run time (experiments).
-#ifndef MG_RB_SHAPES
-#define MG_RB_SHAPES 1
-#endif
-inline int rb_shape() {
-  static const int s = [] { const char* e = std::getenv("MG_RB_SHAPE"); return e ? std::atoi(e) : 0; }();
-  return (s >= 0 && s < MG_RB_SHAPES) ? s : 0;
-}
 template <typename T, int HALO, int W, int RPT>
 mg::FusedArgs rb_args(const LegGeom& g, bool use_div) {
   using S = mg::RbShape<T, HALO, W, RPT>;
@@ -468,7 +460,7 @@ mg::FusedArgs rb_args(const LegGeom& g, bool use_div) {
   return a;
 }
 // g.rb: 0 never, 1 on levels above ~1100^2 cells (where a launch is bandwidth-bound), 2 on every level (tests)
-inline bool use_rb(const LegGeom& g, int sm) { return !g.acoef && (g.rb == 2 || (g.rb == 1 && !small_tiles(g, sm))); }
+inline bool use_rb(const LegGeom& g, int) { return g.rb == 2 || (g.rb == 1 && (long long)g.nx * g.ny > 1100LL * 1100LL); }
 
 // Arrays of more than ~100 MB cannot stay in the 256 MiB Infinity Cache from one leg to the next (u, t and rhs compete):
 // their legs run with streaming hints (rb_leg_kernel TAG 2).  MG_RB_NT=0/1 overrides (experiments).
@@ -477,72 +469,68 @@ inline bool rb_stream(const LegGeom& g, size_t esz) {
   if (force >= 0) return force != 0;
   return (size_t)g.nx * g.ld * esz > (size_t)100 << 20;
 }
-template <typename T, typename TX, int SM, int W, int RPT>
+// kernel variant by streaming hints (TAG 2) -- VAR is a template argument of the launcher so that only the shapes in use
+// are instantiated: constant coefficients 4 waves x 8 rows, variable coefficients 8 waves x 4 rows (the same 32-row
+// region; the face means of 4 rows per lane keep the kernel at ~120 VGPRs instead of 256)
+#define MG_RB_PICK(nt, ...) ((nt) ? mg::rb_leg_kernel<__VA_ARGS__, 2, SM, W, RPT, VAR> : mg::rb_leg_kernel<__VA_ARGS__, 1, SM, W, RPT, VAR>)
+template <typename T, typename TX, int SM, int W, int RPT, bool VAR>
 void launch_down_rb_s(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
   constexpr int HALO = 2 * mg::sweep_halo(SM) + 2;
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
   const bool nt = rb_stream(g, sizeof(T));
-  auto k = zero_init ? (nt ? mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 2, SM, W, RPT>
-                           : mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 1, SM, W, RPT>)
-                     : (nt ? mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 2, SM, W, RPT>
-                           : mg::rb_leg_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 1, SM, W, RPT>);
+  auto k = zero_init ? MG_RB_PICK(nt, T, HALO, false, mg::kPostRestrict, true, TX, T)
+                     : MG_RB_PICK(nt, T, HALO, false, mg::kPostRestrict, false, TX, T);
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr, (TX*)rhs_c,
-                     (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+                     (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff,
+                     (const T*)g.acoef, (T)g.sigma);
 }
-template <typename T, typename TX, typename TC, int SM, int W, int RPT>
+template <typename T, typename TX, typename TC, int SM, int W, int RPT, bool VAR>
 int launch_up_rb_s(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm, hipStream_t st) {
   const Coef c = coefs(g.hx, g.hy, g.sigma);
+  const bool nt = rb_stream(g, sizeof(T));
   if (norm) {
     constexpr int HALO = 2 * mg::sweep_halo(SM) + 1;
     const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
-    auto k = rb_stream(g, sizeof(T)) ? mg::rb_leg_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 2, SM, W, RPT>
-                                     : mg::rb_leg_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 1, SM, W, RPT>;
+    auto k = MG_RB_PICK(nt, T, HALO, true, mg::kPostNorm, false, TX, TC);
     hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                        (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c, (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
-                       (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+                       (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff, (const T*)g.acoef, (T)g.sigma);
     return a.ntiles;
   }
   constexpr int HALO = 2 * mg::sweep_halo(SM);
   const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
-  auto k = rb_stream(g, sizeof(T)) ? mg::rb_leg_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 2, SM, W, RPT>
-                                   : mg::rb_leg_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 1, SM, W, RPT>;
+  auto k = MG_RB_PICK(nt, T, HALO, true, mg::kPostNone, false, TX, TC);
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                      (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c, (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
-                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff, (const T*)g.acoef, (T)g.sigma);
   return 0;
 }
-template <typename T, int SM, int W, int RPT>
+template <typename T, int SM, int W, int RPT, bool VAR>
 void launch_sweeps_rb_s(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
   constexpr int HALO = 2 * mg::sweep_halo(SM);
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   const mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
-  auto k = rb_stream(g, sizeof(T)) ? mg::rb_leg_kernel<T, HALO, false, mg::kPostNone, false, T, T, 2, SM, W, RPT>
-                                   : mg::rb_leg_kernel<T, HALO, false, mg::kPostNone, false, T, T, 1, SM, W, RPT>;
+  const bool nt = rb_stream(g, sizeof(T));
+  auto k = MG_RB_PICK(nt, T, HALO, false, mg::kPostNone, false, T, T);
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                      (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr, (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
-                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0);
+                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0, (const T*)g.acoef, (T)g.sigma);
 }
-// shape table: 0 = 4 waves x 8 rows (four workgroups per CU: the best overlap of loads and arithmetic measured), 1 = 8 x 8
-#if MG_RB_SHAPES > 1
-#define MG_RB_DISPATCH(CALL4x8, CALL8x8) \
-  switch (rb_shape()) { case 1: CALL8x8; break; default: CALL4x8; }
-#else
-#define MG_RB_DISPATCH(CALL4x8, CALL8x8) CALL4x8;
-#endif
 template <typename T, typename TX, int SM>
 void launch_down_rb(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
-  MG_RB_DISPATCH((launch_down_rb_s<T, TX, SM, 4, 8>(u, rhs, out, rhs_c, g, zero_init, st)), (launch_down_rb_s<T, TX, SM, 8, 8>(u, rhs, out, rhs_c, g, zero_init, st)))
+  if (g.acoef) launch_down_rb_s<T, TX, SM, 8, 4, true>(u, rhs, out, rhs_c, g, zero_init, st);
+  else launch_down_rb_s<T, TX, SM, 4, 8, false>(u, rhs, out, rhs_c, g, zero_init, st);
 }
 template <typename T, typename TX, typename TC, int SM>
 int launch_up_rb(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm, hipStream_t st) {
-  int n = 0;
-  MG_RB_DISPATCH((n = launch_up_rb_s<T, TX, TC, SM, 4, 8>(u, rhs, out, e_c, partials, g, norm, st)), (n = launch_up_rb_s<T, TX, TC, SM, 8, 8>(u, rhs, out, e_c, partials, g, norm, st)))
-  return n;
+  return g.acoef ? launch_up_rb_s<T, TX, TC, SM, 8, 4, true>(u, rhs, out, e_c, partials, g, norm, st)
+                 : launch_up_rb_s<T, TX, TC, SM, 4, 8, false>(u, rhs, out, e_c, partials, g, norm, st);
 }
 template <typename T, int SM>
 void launch_sweeps_rb(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
-  MG_RB_DISPATCH((launch_sweeps_rb_s<T, SM, 4, 8>(u, rhs, out, g, st)), (launch_sweeps_rb_s<T, SM, 8, 8>(u, rhs, out, g, st)))
+  if (g.acoef) launch_sweeps_rb_s<T, SM, 8, 4, true>(u, rhs, out, g, st);
+  else launch_sweeps_rb_s<T, SM, 4, 8, false>(u, rhs, out, g, st);
 }
 
 // One weighted-Jacobi sweep on a level above ~1100^2 cells: the register-blocked sweeps kernel with nsweep = 1 (same
@@ -1879,14 +1867,14 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
                   if (d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], v.u[dt], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE; } break;
         case 6: { const int rc = run_cycle(h); if (rc != MG_OK) return rc; } break;
         case 7: { Level& c = h->lv[level + 1]; const int dc = c.rhs[dt] ? dt : 1 - dt;          // down leg
-                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h);
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) g.acoef = v.a[dt];
                   d_down(h->cfg.smoother, dt, dc, v.u[dt], v.rhs[dt], v.t[dt], c.rhs[dc], g, false, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         case 8: { Level& c = h->lv[level + 1]; const int dc = c.u[dt] ? dt : 1 - dt;            // up leg (+ norm on level 0)
-                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h);
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) g.acoef = v.a[dt];
                   if (d_up(h->cfg.smoother, dt, dc, h->grid_dtype, v.u[dt], v.rhs[dt], v.t[dt], c.u[dc], h->partials, g, level == 0, h->stream) < 0) return MG_ERR_INVALID_VALUE;
                   std::swap(v.u[dt], v.t[dt]); } break;
-        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h);
+        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) g.acoef = v.a[dt];
                   d_sweeps(h->cfg.smoother, dt, v.u[dt], v.rhs[dt], v.t[dt], g, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         default: return MG_ERR_INVALID_VALUE;

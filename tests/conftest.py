@@ -49,3 +49,9 @@ def golden_solves():
 def golden_large():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "large_1025.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_large4097():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "large_4097.npz"))

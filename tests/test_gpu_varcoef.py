@@ -125,7 +125,7 @@ def test_var_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post, s
     u0 = rng.standard_normal((nx, ny))
     a = np.exp(0.6 * rng.standard_normal((nx, ny)))                 # rough, positive: nothing cancels by symmetry
     res = []
-    for fused, tail in ((True, True), (True, False), (False, False)):
+    for fused, tail in ((1, True), (1, False), (0, False), (3, True)):      # 3: the register-blocked legs on every level
         eng = mg.MultigridEngine(nx, ny, max_levels=mg.default_max_levels(nx, ny), cycle=cyc, pre=pre, post=post,
                                  smoother=_lib.MG_JACOBI if sm == "jacobi" else _lib.MG_RBGS, omega=omega, precision=code,
                                  switch_threshold=1e-3, coarse_maxit=60, fused=fused, tail=tail, speculate=tail)
@@ -133,9 +133,11 @@ def test_var_fused_legs_equal_one_launch_per_operator(prec, n, cyc, pre, post, s
         u, r = eng.solve(rhs, u0, tol=1e-30, max_iterations=5)
         eng.close()
         res.append((u, r))
-    (ut, rt), (uf, rf), (uu, ru) = res
+    (ut, rt), (uf, rf), (uu, ru), (ub, rb) = res
     np.testing.assert_array_equal(uf, uu)
     np.testing.assert_array_equal(ut, uu)
+    np.testing.assert_array_equal(ub, uu)
+    np.testing.assert_allclose(rb["residual_history"], ru["residual_history"], rtol=1e-11)
     np.testing.assert_allclose(rf["residual_history"], ru["residual_history"], rtol=1e-11)
     np.testing.assert_allclose(rt["residual_history"], ru["residual_history"], rtol=1e-11)
     assert rf["precision_codes"] == ru["precision_codes"] == rt["precision_codes"]

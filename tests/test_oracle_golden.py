@@ -146,3 +146,19 @@ def test_c_oracle_equals_numpy_oracle(n, levels, cyc, kind, omega):
     assert np.max(np.abs(got - u)) <= 1e-13 * np.max(np.abs(u))      # the coarsest stop test may differ by one sweep
     np.testing.assert_allclose(co.residual_norm(), ref.residual_norm(u, rhs, 0), rtol=1e-9)
     co.close()
+
+
+def test_oracle_equals_reference_at_the_bench_size(golden_large4097):
+    """oracle == reference at 4097^2 (BASELINE config 3's grid): two V(2,2) Jacobi cycles, history and a strided sample."""
+    n = 4097
+    g = golden_large4097
+    mgo = O.MGOracle(n, n, max_levels=11, cycle="V", smoother="jacobi", omega=0.8, jacobi_form="vectorized")
+    rhs = O.sine_rhs(n, n)
+    mgo.rhs[0] = rhs.copy()
+    u = np.zeros_like(rhs)
+    hist = []
+    for _ in range(2):
+        u = mgo.cycle_once(u, 0)
+        hist.append(mgo.residual_norm(u, rhs, 0))
+    np.testing.assert_allclose(hist, g["hist"], rtol=1e-12)
+    assert np.max(np.abs(u[::128, ::128] - g["u_sample"])) <= 1e-13 * float(g["u_linf"])
