@@ -64,6 +64,68 @@ template <> __device__ __forceinline__ double dpp_from_upper_lane<double>(double
                           __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true));
 }
 
+// The per-row arithmetic of the constant-coefficient stages.  Generic form: the scalar expressions of the single-operator
+// kernels, cell by cell.  fp32 form: the SAME expressions on two-cell vectors, which hipcc lowers to v_pk_add_f32 /
+// v_pk_mul_f32 (two IEEE operations per lane and instruction, each rounded exactly like its scalar twin; no contraction:
+// -ffp-contract=off) -- the fp32 legs are instruction-bound, so halving their arithmetic instructions is time.
+template <typename T, int N> struct RowMath {
+  // res = (1 - w) mid + w (f + ihx2 (dn + up) + ihy2 (east + west)) / D          (solvers/smoothers.py:62-84)
+  static __device__ __forceinline__ Pack<T> relax(const Pack<T>& mid, const Pack<T>& dn, const Pack<T>& up, T left, T right,
+                                                  const Pack<T>& f, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, bool use_div) {
+    Pack<T> res;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
+      const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
+      const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + wv);
+      const T un = use_div ? (f.v[e] + nb) / D : (f.v[e] + nb) * invD;
+      res.v[e] = one_m_omega * mid.v[e] + omega * un;
+    }
+    return res;
+  }
+  // r = f - coeff (((dn + up) ihx2 + (east + west) ihy2) - mid D)                 (operators/laplacian.py:73-77, 117-118)
+  static __device__ __forceinline__ Pack<T> resid(const Pack<T>& mid, const Pack<T>& dn, const Pack<T>& up, T left, T right,
+                                                  const Pack<T>& f, T ihx2, T ihy2, T D, T coeff) {
+    Pack<T> r;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
+      const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
+      const T au = coeff * (((dn.v[e] + up.v[e]) * ihx2 + (ea + wv) * ihy2) - mid.v[e] * D);
+      r.v[e] = f.v[e] - au;
+    }
+    return r;
+  }
+};
+template <> struct RowMath<float, 4> {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ Pack<float> relax(const Pack<float>& mid, const Pack<float>& dn, const Pack<float>& up, float left,
+                                                      float right, const Pack<float>& f, float ihx2, float ihy2, float invD, float D,
+                                                      float omega, float one_m_omega, bool use_div) {
+    const f2 m0 = {mid.v[0], mid.v[1]}, m1 = {mid.v[2], mid.v[3]};
+    const f2 sx0 = f2{dn.v[0], dn.v[1]} + f2{up.v[0], up.v[1]}, sx1 = f2{dn.v[2], dn.v[3]} + f2{up.v[2], up.v[3]};
+    const f2 sy0 = f2{mid.v[1], mid.v[2]} + f2{left, mid.v[0]}, sy1 = f2{mid.v[3], right} + f2{mid.v[1], mid.v[2]};   // (east + west)
+    const f2 nb0 = ihx2 * sx0 + ihy2 * sy0, nb1 = ihx2 * sx1 + ihy2 * sy1;
+    const f2 t0 = f2{f.v[0], f.v[1]} + nb0, t1 = f2{f.v[2], f.v[3]} + nb1;
+    const f2 un0 = use_div ? t0 / D : t0 * invD, un1 = use_div ? t1 / D : t1 * invD;
+    const f2 r0 = one_m_omega * m0 + omega * un0, r1 = one_m_omega * m1 + omega * un1;
+    Pack<float> res;
+    res.v[0] = r0.x; res.v[1] = r0.y; res.v[2] = r1.x; res.v[3] = r1.y;
+    return res;
+  }
+  static __device__ __forceinline__ Pack<float> resid(const Pack<float>& mid, const Pack<float>& dn, const Pack<float>& up, float left,
+                                                      float right, const Pack<float>& f, float ihx2, float ihy2, float D, float coeff) {
+    const f2 m0 = {mid.v[0], mid.v[1]}, m1 = {mid.v[2], mid.v[3]};
+    const f2 sx0 = f2{dn.v[0], dn.v[1]} + f2{up.v[0], up.v[1]}, sx1 = f2{dn.v[2], dn.v[3]} + f2{up.v[2], up.v[3]};
+    const f2 sy0 = f2{mid.v[1], mid.v[2]} + f2{left, mid.v[0]}, sy1 = f2{mid.v[3], right} + f2{mid.v[1], mid.v[2]};
+    const f2 au0 = coeff * ((sx0 * ihx2 + sy0 * ihy2) - m0 * D), au1 = coeff * ((sx1 * ihx2 + sy1 * ihy2) - m1 * D);
+    const f2 r0 = f2{f.v[0], f.v[1]} - au0, r1 = f2{f.v[2], f.v[3]} - au1;
+    Pack<float> r;
+    r.v[0] = r0.x; r.v[1] = r0.y; r.v[2] = r1.x; r.v[3] = r1.y;
+    return r;
+  }
+};
+
 // Exchange of the strips' edge rows: every wave publishes its first and last row, then reads the last row of the wave
 // above and the first row of the wave below (zeros beyond the region).  `xb`: W x 2 x 64 packs.
 template <typename T, int W>
@@ -214,7 +276,16 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
       Pack<T> o = mid;
       const bool row_ok = INT ? ((k > 0 || w > 0) && (k < RPT - 1 || w < W - 1))
                               : (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1);
-      if (row_ok) {
+      if (row_ok && !VAR) {
+        const Pack<T> res = RowMath<T, N>::relax(mid, dn, prev, left, right, F[k], ihx2, ihy2, invD, D, omega, one_m_omega, a.use_div != 0);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const int gj = gj0 + e;
+          const bool mine = (SM != kSmRbgs) || (((par0 + k + e) & 1) == colour);
+          if ((INT || (gj >= 1 && gj < a.ny - 1)) && mine) o.v[e] = res.v[e];
+        }
+      }
+      if (row_ok && VAR) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
@@ -272,7 +343,19 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
       const bool wanted = (POST == kPostRestrict) || in_tile;        // the norm only needs r on the tile itself
       const bool row_ok = INT ? ((k > 0 || w > 0) && (k < RPT - 1 || w < W - 1))
                               : (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1);
-      if (wanted && row_ok) {
+      if (wanted && row_ok && !VAR) {
+        const Pack<T> rr = RowMath<T, N>::resid(mid, dn, up, left, right, F[k], ihx2, ihy2, D, coeff);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const int gj = gj0 + e;
+          if (INT || (gj >= 1 && gj < a.ny - 1)) {
+            o.v[e] = rr.v[e];
+            if (POST == kPostNorm && in_tile && (INT || (gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi)))
+              acc += (double)o.v[e] * (double)o.v[e];
+          }
+        }
+      }
+      if (wanted && row_ok && VAR) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];

@@ -163,3 +163,16 @@ def test_size_independent_properties_at_bench_size():
     assert np.all(s[3:-3, 3:-3] == 0)
     # norm of ones: sqrt(hx*hy*n^2)
     np.testing.assert_allclose(grid.l2_norm(ones), n / (n - 1), rtol=1e-12)
+
+
+@pytest.mark.parametrize("shape", [(4097, 4097), (4500, 4097)])
+def test_single_sweep_on_hbm_sized_arrays_equals_oracle(shape):
+    """Arrays beyond the Infinity Cache (4097^2 fp64 = 136 MB each) take the register-blocked single sweep with streaming
+    hints (jacobi_rb) instead of the LDS-tiled jacobi_kernel: same bits as the oracle, ring passed through."""
+    nx, ny = shape
+    rng = np.random.default_rng(nx)
+    u = rng.standard_normal(shape); f = rng.standard_normal(shape)
+    hx, hy = O.grid_spacing(nx, ny)
+    grid = mg.Grid(nx, ny)
+    got = mg.JacobiSmoother(relaxation_parameter=0.8).smooth(grid, NEG, u, f, 3)
+    np.testing.assert_array_equal(got, O.jacobi(u, f, hx, hy, 0.8, 3, "vectorized"))
