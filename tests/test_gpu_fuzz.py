@@ -65,7 +65,7 @@ def test_random_shapes_cycles(k, nx, ny, domain, dyadic):
     ref = O.MGOracle(nx, ny, domain, max_levels=levels, cycle=cyc, smoother=kind, omega=omega)
     u_ref, info = ref.solve(rhs, u0, tol=0.0, max_iterations=2)
     outs = []
-    for fused in (True, False):
+    for fused in (1, 0, 3):          # LDS-tiled legs, one launch per operator, register-blocked legs on every level
         eng = mg.MultigridEngine(nx, ny, domain=domain, max_levels=levels, cycle=cyc,
                                  smoother=_lib.MG_JACOBI if kind == "jacobi" else _lib.MG_RBGS, omega=omega, fused=fused)
         assert eng.shapes == ref.shapes
@@ -76,6 +76,33 @@ def test_random_shapes_cycles(k, nx, ny, domain, dyadic):
         # (a tiny grid is solved to rounding level by the coarsest solver alone: compare such norms absolutely)
         np.testing.assert_allclose(r["residual_history"], info["residual_history"], rtol=1e-8, atol=1e-11 * np.max(np.abs(rhs)))
     np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[2], outs[1])
+
+
+@pytest.mark.parametrize("k,nx,ny,domain,dyadic", _cases(int(os.environ.get("MG_FUZZ_CYCLES", 16)), int(os.environ.get("MG_FUZZ_SEED", 2024)) + 29))
+def test_random_shapes_cycles_single_precision_and_variable_coefficient(k, nx, ny, domain, dyadic):
+    """The same random shapes in fp32 (packed arithmetic of the register-blocked legs, true divisions on non-dyadic
+    domains) and with a rough coefficient field: LDS-tiled == per operator == register-blocked, bit for bit."""
+    rng = np.random.default_rng(5000 + k)
+    cyc = ["V", "W"][k % 2]
+    kind, omega = [("jacobi", 0.8), ("rbgs", 1.0), ("rbgs", 1.2)][(k // 2) % 3]
+    levels = min(mg.default_max_levels(nx, ny), 6)
+    rhs = rng.standard_normal((nx, ny)); u0 = rng.standard_normal((nx, ny))
+    a = np.exp(0.5 * rng.standard_normal((nx, ny))) if k % 3 == 0 else None
+    prec = _lib.MG_PREC_SINGLE if k % 2 else _lib.MG_PREC_SINGLE_MANAGED
+    outs = []
+    for fused in (1, 0, 3):
+        eng = mg.MultigridEngine(nx, ny, domain=domain, max_levels=levels, cycle=cyc, smoother=_lib.MG_JACOBI if kind == "jacobi" else _lib.MG_RBGS,
+                                 omega=omega, precision=prec, coarse_maxit=40, fused=fused)
+        if a is not None:
+            eng.set_coefficient(a)
+        u, r = eng.solve(rhs, u0, tol=0.0, max_iterations=2)
+        eng.close()
+        outs.append((u, r["residual_history"]))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[2][0], outs[1][0])
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-11)
+    np.testing.assert_allclose(outs[2][1], outs[1][1], rtol=1e-11)
 
 
 def _dd_cases(n, seed):
