@@ -276,6 +276,58 @@ int mg_dev_scratch_bytes(int nx, int ny, int64_t* bytes);
 /* pitch (elements) the library itself uses for an (nx, ny) field of `dtype` */
 int mg_pitch_elems(int dtype, int ny, int* ld);
 
+/* ------------------------------------------------------------------------------------------------
+ * Cycle plans: one decomposed V/W/F cycle of one rank as a flat list of operations, replayed natively.
+ * The reference's counterpart is the per-cycle Python of its (never-running) DistributedMultigridSolver /
+ * halo exchange (gpu/multi_gpu.py:380-460); here the host side records the list once -- pointers, shapes,
+ * peers and stream assignment of everything `DistributedMultigrid.cycle()` issues -- and every later cycle is ONE call:
+ * kernel launches, halo copies, RCCL send/recv groups, the coarse gather, the replicated engine's cycle and the norm
+ * all-reduce are enqueued from C++ on two HIP streams.  All pointers are device pointers owned by the caller and must
+ * outlive the plan.  Slots not listed for an operation are ignored.
+ * ------------------------------------------------------------------------------------------------ */
+enum {
+  MG_PLAN_DOWN_LEG = 1,    /* i: smoother, dtype, coarse_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off, cj_off, nsweep, zero_init,
+                                 colour_offset, select, has_rect, rect[4];  d: hx, hy, omega, coeff;
+                                 p: u, rhs, out, rhs_coarse, acoef                                   (mg_dev_down_leg_var) */
+  MG_PLAN_UP_LEG = 2,      /* i: smoother, dtype, coarse_dtype, compute_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off, cj_off, sides,
+                                 nsweep, colour_offset, norm, window[4];  d: hx, hy, omega, coeff;
+                                 p: u, rhs, out, e_coarse, scratch, sumsq_dev, acoef                 (mg_dev_up_leg_var) */
+  MG_PLAN_COPY2D = 3,      /* i: rows, width_bytes, dst_pitch_bytes, src_pitch_bytes;  p: dst, src   (4-byte granularity) */
+  MG_PLAN_ADD_F64 = 4,     /* p: dst, a, b:  *dst = *a + *b   (device doubles; b NULL: *dst = *a) */
+  MG_PLAN_GROUP_BEGIN = 5, /* ncclGroupStart */
+  MG_PLAN_SEND = 6,        /* i: peer, bytes;  p: buffer */
+  MG_PLAN_RECV = 7,        /* i: peer, bytes;  p: buffer */
+  MG_PLAN_GROUP_END = 8,   /* ncclGroupEnd */
+  MG_PLAN_ALLGATHER = 9,   /* i: bytes per rank;  p: send, recv */
+  MG_PLAN_ALLREDUCE_F64 = 10, /* i: count;  p: buffer (in place, sum) */
+  MG_PLAN_COARSE_BEGIN = 11,  /* i: ld, dtype;  p: engine handle, rhs   (stream, rhs, zero iterate) */
+  MG_PLAN_COARSE_CYCLE = 12,  /* i: cycles;  p: engine handle */
+  MG_PLAN_COARSE_END = 13,    /* i: ld, dtype;  p: engine handle, out */
+  MG_PLAN_EVENT_RECORD = 14,  /* i: event id (0..7) on the operation's stream */
+  MG_PLAN_STREAM_WAIT = 15,   /* i: event id: the operation's stream waits for it */
+  MG_PLAN_RESULT = 16         /* p: device double copied to the host at the end of mg_plan_run (at most one) */
+};
+typedef struct mg_plan_op {
+  int32_t op;       /* MG_PLAN_* */
+  int32_t stream;   /* 0: compute stream, 1: communication stream */
+  int32_t i[24];
+  double d[4];
+  void* p[8];
+} mg_plan_op;
+typedef struct mg_plan mg_plan;
+/* comm: an RCCL communicator from mg_comm_init, or NULL for a plan without SEND/RECV/ALLGATHER/ALLREDUCE operations */
+int mg_plan_create(const mg_plan_op* ops, int n_ops, void* comm, int device, mg_plan** out);
+/* enqueue every operation; when the plan has a RESULT, wait for it and store it in *result */
+int mg_plan_run(mg_plan* plan, void* compute_stream, void* comm_stream, double* result);
+int mg_plan_num_ops(const mg_plan* plan, int* n);
+const char* mg_plan_error(const mg_plan* plan);   /* NULL plan: the last mg_comm_* / mg_plan_create error of this thread */
+int mg_plan_destroy(mg_plan* plan);
+/* RCCL through the library the process already uses (`rccl_library`: path of librccl.so, e.g. torch's own copy).
+ * mg_comm_unique_id fills 128 bytes on one rank; every rank passes the same bytes to mg_comm_init. */
+int mg_comm_unique_id(const char* rccl_library, void* id128);
+int mg_comm_init(const char* rccl_library, const void* id128, int nranks, int rank, int device, void** comm);
+int mg_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

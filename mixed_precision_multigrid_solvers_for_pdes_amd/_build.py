@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmghip.so")
-SOURCES = [os.path.join(CSRC, "mghip.hip")]
+SOURCES = [os.path.join(CSRC, "mghip.hip"), os.path.join(CSRC, "mg_plan.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, "mg_kernels.hpp"), os.path.join(CSRC, "mg_rb_kernels.hpp"),
                   os.path.join(os.path.dirname(HERE), "include", "mghip.h")]
 # -ffp-contract=off: the kernels reproduce the reference's rounding sequence (no FMA contraction).

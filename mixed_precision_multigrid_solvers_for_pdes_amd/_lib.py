@@ -43,6 +43,15 @@ class MgStats(C.Structure):
     ]
 
 
+class MgPlanOp(C.Structure):
+    """mg_plan_op (include/mghip.h, "Cycle plans")"""
+    _fields_ = [("op", C.c_int32), ("stream", C.c_int32), ("i", C.c_int32 * 24), ("d", C.c_double * 4), ("p", C.c_void_p * 8)]
+
+
+(MG_PLAN_DOWN_LEG, MG_PLAN_UP_LEG, MG_PLAN_COPY2D, MG_PLAN_ADD_F64, MG_PLAN_GROUP_BEGIN, MG_PLAN_SEND, MG_PLAN_RECV,
+ MG_PLAN_GROUP_END, MG_PLAN_ALLGATHER, MG_PLAN_ALLREDUCE_F64, MG_PLAN_COARSE_BEGIN, MG_PLAN_COARSE_CYCLE, MG_PLAN_COARSE_END,
+ MG_PLAN_EVENT_RECORD, MG_PLAN_STREAM_WAIT, MG_PLAN_RESULT) = range(1, 17)
+
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
 _pi, _pd = C.POINTER(C.c_int), C.POINTER(C.c_double)
 
@@ -102,6 +111,14 @@ SIGNATURES = {
     "mg_dev_inject_ring": (_i, [_i] * 11 + [_vp] * 3),
     "mg_dev_scratch_bytes": (_i, [_i, _i, C.POINTER(C.c_int64)]),
     "mg_pitch_elems": (_i, [_i, _i, _pi]),
+    "mg_plan_create": (_i, [C.POINTER(MgPlanOp), _i, _vp, _i, C.POINTER(_vp)]),
+    "mg_plan_run": (_i, [_vp, _vp, _vp, _pd]),
+    "mg_plan_num_ops": (_i, [_vp, _pi]),
+    "mg_plan_error": (C.c_char_p, [_vp]),
+    "mg_plan_destroy": (_i, [_vp]),
+    "mg_comm_unique_id": (_i, [C.c_char_p, _vp]),
+    "mg_comm_init": (_i, [C.c_char_p, _vp, _i, _i, _i, C.POINTER(_vp)]),
+    "mg_comm_destroy": (_i, [_vp]),
 }
 
 _lib = None
@@ -185,6 +202,17 @@ def check(rc, handle=None):
         raise MemoryError(msg)
     if rc == MG_ERR_NO_DEVICE:
         raise RuntimeError("mghip: no usable HIP device (the multigrid path has no CPU fallback): " + msg)
+    raise RuntimeError("mghip: " + msg)
+
+
+def check_plan(rc, plan=None):
+    """status of a mg_plan_* / mg_comm_* call"""
+    if rc == MG_OK:
+        return
+    msg = load().mg_plan_error(plan)
+    msg = (msg.decode() if msg else "") or f"mghip plan error {rc}"
+    if rc == MG_ERR_INVALID_VALUE:
+        raise ValueError(msg)
     raise RuntimeError("mghip: " + msg)
 
 

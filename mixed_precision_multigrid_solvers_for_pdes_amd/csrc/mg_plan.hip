@@ -1,0 +1,356 @@
+// Cycle plans (include/mghip.h, "Cycle plans"): the decomposed solver's per-cycle work of one rank, recorded once by
+// the host side and replayed here with one call per cycle -- fused legs, halo copies, RCCL groups, the coarse gather,
+// the replicated engine and the norm all-reduce, on two HIP streams.  Uses only the public entry points of the library
+// plus RCCL, which is resolved at run time from the copy the process already has loaded (no link-time dependency).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mghip.h"
+
+namespace {
+
+thread_local std::string g_plan_error;
+
+int plan_fail(std::string* where, int code, const std::string& msg) {
+  if (where) *where = msg;
+  g_plan_error = msg;
+  return code;
+}
+
+// ---- RCCL, resolved by name ------------------------------------------------------------------
+// The handful of declarations used here, as rccl.h (NCCL 2.x API) has them.
+typedef struct ncclComm* ncclComm_t;
+struct NcclId { char internal[128]; };
+enum { kNcclInt8 = 0, kNcclFloat64 = 8, kNcclSum = 0 };
+
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(NcclId*) = nullptr;
+  int (*CommInitRank)(ncclComm_t*, int, NcclId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl(const char* path) {
+  if (g_rccl.lib) return MG_OK;
+  void* lib = dlopen(path && *path ? path : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return plan_fail(nullptr, MG_ERR_STATE, std::string("cannot load RCCL: ") + dlerror());
+  Rccl r;
+  r.lib = lib;
+  bool ok = true;
+  auto sym = [&](const char* name) { void* s = dlsym(lib, name); ok = ok && s; return s; };
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+  r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+  r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+  r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+  if (!ok) return plan_fail(nullptr, MG_ERR_STATE, "the RCCL library lacks a symbol of the NCCL 2 API");
+  g_rccl = r;
+  return MG_OK;
+}
+
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int nranks = 0, rank = 0, device = 0;
+};
+
+// ---- device helpers --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy2d_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int rows,
+                                                     int width_words, int64_t dst_pitch_words, int64_t src_pitch_words) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < width_words; c += gridDim.x * 256)
+    dst[r * dst_pitch_words + c] = src[r * src_pitch_words + c];
+  (void)rows;
+}
+
+__global__ void add_f64_kernel(double* dst, const double* a, const double* b) { *dst = b ? *a + *b : *a; }
+
+}  // namespace
+
+struct mg_plan {
+  std::vector<mg_plan_op> ops;
+  Comm* comm = nullptr;
+  int device = 0;
+  hipEvent_t ev[8] = {};
+  double* result_dev = nullptr;
+  double* result_host = nullptr;       // pinned
+  std::string err;
+};
+
+namespace {
+
+#define PLAN_HIP(plan, call)                                                                                           \
+  do {                                                                                                                 \
+    hipError_t e_ = (call);                                                                                            \
+    if (e_ != hipSuccess)                                                                                              \
+      return plan_fail(&(plan)->err, MG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+  } while (0)
+
+int nccl_fail(mg_plan* p, int rc, const char* what) {
+  return plan_fail(&p->err, MG_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+}
+
+bool needs_comm(int op) {
+  return op == MG_PLAN_GROUP_BEGIN || op == MG_PLAN_GROUP_END || op == MG_PLAN_SEND || op == MG_PLAN_RECV ||
+         op == MG_PLAN_ALLGATHER || op == MG_PLAN_ALLREDUCE_F64;
+}
+
+int check_op(const mg_plan_op& o, int idx, std::string* err) {
+  auto bad = [&](const char* why) { return plan_fail(err, MG_ERR_INVALID_VALUE, "plan op " + std::to_string(idx) + ": " + why); };
+  if (o.stream != 0 && o.stream != 1) return bad("stream must be 0 or 1");
+  switch (o.op) {
+    case MG_PLAN_DOWN_LEG:
+      if (!o.p[1] || !o.p[2] || !o.p[3] || (!o.i[12] && !o.p[0])) return bad("down leg: NULL field");
+      return MG_OK;
+    case MG_PLAN_UP_LEG:
+      if (!o.p[0] || !o.p[1] || !o.p[2] || !o.p[3] || (o.i[15] && (!o.p[4] || !o.p[5]))) return bad("up leg: NULL field");
+      return MG_OK;
+    case MG_PLAN_COPY2D:
+      if (!o.p[0] || !o.p[1] || o.i[0] < 0 || o.i[1] < 0 || (o.i[1] & 3) || (o.i[2] & 3) || (o.i[3] & 3) ||
+          (reinterpret_cast<uintptr_t>(o.p[0]) & 3) || (reinterpret_cast<uintptr_t>(o.p[1]) & 3) ||
+          (o.i[0] > 1 && (o.i[2] < o.i[1] || o.i[3] < o.i[1])))
+        return bad("copy2d: NULL pointer, or sizes / pitches / pointers that are not multiples of 4 bytes");
+      return MG_OK;
+    case MG_PLAN_ADD_F64:
+      return (o.p[0] && o.p[1]) ? MG_OK : bad("add: NULL pointer");
+    case MG_PLAN_GROUP_BEGIN:
+    case MG_PLAN_GROUP_END:
+      return MG_OK;
+    case MG_PLAN_SEND:
+    case MG_PLAN_RECV:
+      return (o.p[0] && o.i[0] >= 0 && o.i[1] >= 0) ? MG_OK : bad("send/recv: NULL buffer or negative peer / size");
+    case MG_PLAN_ALLGATHER:
+      return (o.p[0] && o.p[1] && o.i[0] >= 0) ? MG_OK : bad("allgather: NULL buffer");
+    case MG_PLAN_ALLREDUCE_F64:
+      return (o.p[0] && o.i[0] >= 1) ? MG_OK : bad("allreduce: NULL buffer");
+    case MG_PLAN_COARSE_BEGIN:
+    case MG_PLAN_COARSE_END:
+      return (o.p[0] && o.p[1]) ? MG_OK : bad("coarse begin/end: NULL handle or field");
+    case MG_PLAN_COARSE_CYCLE:
+      return (o.p[0] && o.i[0] >= 0) ? MG_OK : bad("coarse cycle: NULL handle");
+    case MG_PLAN_EVENT_RECORD:
+    case MG_PLAN_STREAM_WAIT:
+      return (o.i[0] >= 0 && o.i[0] < 8) ? MG_OK : bad("event id out of range");
+    case MG_PLAN_RESULT:
+      return o.p[0] ? MG_OK : bad("result: NULL pointer");
+    default:
+      return bad("unknown operation");
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mg_plan_error(const mg_plan* plan) { return plan ? plan->err.c_str() : g_plan_error.c_str(); }
+
+int mg_comm_unique_id(const char* rccl_library, void* id128) {
+  if (!id128) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_comm_unique_id: NULL argument");
+  if (int rc = load_rccl(rccl_library)) return rc;
+  NcclId id;
+  const int rc = g_rccl.GetUniqueId(&id);
+  if (rc != 0) return plan_fail(nullptr, MG_ERR_HIP, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(rc));
+  std::memcpy(id128, id.internal, sizeof(id.internal));
+  return MG_OK;
+}
+
+int mg_comm_init(const char* rccl_library, const void* id128, int nranks, int rank, int device, void** comm) {
+  if (!id128 || !comm || nranks < 1 || rank < 0 || rank >= nranks)
+    return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_comm_init: bad argument");
+  *comm = nullptr;
+  if (int rc = load_rccl(rccl_library)) return rc;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return plan_fail(nullptr, MG_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  NcclId id;
+  std::memcpy(id.internal, id128, sizeof(id.internal));
+  Comm* c = new Comm;
+  c->nranks = nranks; c->rank = rank; c->device = device;
+  const int rc = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+  if (rc != 0) {
+    delete c;
+    return plan_fail(nullptr, MG_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc));
+  }
+  *comm = c;
+  return MG_OK;
+}
+
+int mg_comm_destroy(void* comm) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (!c) return MG_OK;
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  delete c;
+  return MG_OK;
+}
+
+int mg_plan_create(const mg_plan_op* ops, int n_ops, void* comm, int device, mg_plan** out) {
+  if (!ops || n_ops < 1 || !out) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_create: bad argument");
+  *out = nullptr;
+  int results = 0, depth = 0;
+  for (int k = 0; k < n_ops; ++k) {
+    if (int rc = check_op(ops[k], k, nullptr)) return rc;
+    if (needs_comm(ops[k].op) && !comm)
+      return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "plan op " + std::to_string(k) + " communicates but the plan has no communicator");
+    if (ops[k].op == MG_PLAN_GROUP_BEGIN) ++depth;
+    if (ops[k].op == MG_PLAN_GROUP_END && --depth < 0) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "GROUP_END without GROUP_BEGIN");
+    if ((ops[k].op == MG_PLAN_SEND || ops[k].op == MG_PLAN_RECV)) {
+      const Comm* c = static_cast<const Comm*>(comm);
+      if (ops[k].i[0] >= c->nranks) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "plan op " + std::to_string(k) + ": peer out of range");
+    }
+    results += (ops[k].op == MG_PLAN_RESULT);
+  }
+  if (depth != 0) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "GROUP_BEGIN without GROUP_END");
+  if (results > 1) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "a plan has at most one RESULT");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return plan_fail(nullptr, MG_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  mg_plan* p = new mg_plan;
+  p->ops.assign(ops, ops + n_ops);
+  p->comm = static_cast<Comm*>(comm);
+  p->device = device;
+  for (auto& ev : p->ev) {
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+  }
+  e = hipHostMalloc(reinterpret_cast<void**>(&p->result_host), sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_ALLOC, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+  *out = p;
+  return MG_OK;
+}
+
+int mg_plan_num_ops(const mg_plan* plan, int* n) {
+  if (!plan || !n) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_num_ops: NULL argument");
+  *n = static_cast<int>(plan->ops.size());
+  return MG_OK;
+}
+
+int mg_plan_destroy(mg_plan* p) {
+  if (!p) return MG_OK;
+  for (auto& ev : p->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (p->result_host) (void)hipHostFree(p->result_host);
+  delete p;
+  return MG_OK;
+}
+
+int mg_plan_run(mg_plan* p, void* compute_stream, void* comm_stream, double* result) {
+  if (!p) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_run: NULL plan");
+  PLAN_HIP(p, hipSetDevice(p->device));
+  hipStream_t st[2] = {static_cast<hipStream_t>(compute_stream), static_cast<hipStream_t>(comm_stream)};
+  const double* result_dev = nullptr;
+  hipStream_t result_stream = st[0];
+  auto lib_fail = [&](int rc, int k, const char* what) {
+    const char* m = mg_last_error(nullptr);
+    return plan_fail(&p->err, rc, "plan op " + std::to_string(k) + " (" + what + "): " + (m ? m : ""));
+  };
+  for (size_t k = 0; k < p->ops.size(); ++k) {
+    const mg_plan_op& o = p->ops[k];
+    hipStream_t s = st[o.stream];
+    const int32_t* i = o.i;
+    switch (o.op) {
+      case MG_PLAN_DOWN_LEG: {
+        const int rc = mg_dev_down_leg_var(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], o.d[0], o.d[1], o.d[2],
+                                           o.d[3], i[11], i[12], i[13], o.p[0], o.p[1], o.p[2], o.p[3], s, i[14],
+                                           i[15] ? &i[16] : nullptr, o.p[4]);
+        if (rc != MG_OK) return lib_fail(rc, static_cast<int>(k), "down leg");
+        break;
+      }
+      case MG_PLAN_UP_LEG: {
+        const int rc = mg_dev_up_leg_var(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], o.d[0], o.d[1],
+                                         o.d[2], o.d[3], i[13], i[14], o.p[0], o.p[1], o.p[2], o.p[3], i[15], i[16], i[17], i[18], i[19],
+                                         o.p[4], static_cast<double*>(o.p[5]), s, o.p[6]);
+        if (rc != MG_OK) return lib_fail(rc, static_cast<int>(k), "up leg");
+        break;
+      }
+      case MG_PLAN_COPY2D: {
+        if (i[0] == 0 || i[1] == 0) break;
+        const int words = i[1] / 4;
+        int gx = (words + 255) / 256;
+        if (gx > 64) gx = 64;
+        copy2d_kernel<<<dim3(gx, i[0]), 256, 0, s>>>(static_cast<uint32_t*>(o.p[0]), static_cast<const uint32_t*>(o.p[1]), i[0], words,
+                                                     i[2] / 4, i[3] / 4);
+        break;
+      }
+      case MG_PLAN_ADD_F64:
+        add_f64_kernel<<<1, 1, 0, s>>>(static_cast<double*>(o.p[0]), static_cast<const double*>(o.p[1]), static_cast<const double*>(o.p[2]));
+        break;
+      case MG_PLAN_GROUP_BEGIN:
+        if (int rc = g_rccl.GroupStart()) return nccl_fail(p, rc, "ncclGroupStart");
+        break;
+      case MG_PLAN_GROUP_END:
+        if (int rc = g_rccl.GroupEnd()) return nccl_fail(p, rc, "ncclGroupEnd");
+        break;
+      case MG_PLAN_SEND:
+        if (int rc = g_rccl.Send(o.p[0], static_cast<size_t>(i[1]), kNcclInt8, i[0], p->comm->comm, s)) return nccl_fail(p, rc, "ncclSend");
+        break;
+      case MG_PLAN_RECV:
+        if (int rc = g_rccl.Recv(o.p[0], static_cast<size_t>(i[1]), kNcclInt8, i[0], p->comm->comm, s)) return nccl_fail(p, rc, "ncclRecv");
+        break;
+      case MG_PLAN_ALLGATHER:
+        if (int rc = g_rccl.AllGather(o.p[0], o.p[1], static_cast<size_t>(i[0]), kNcclInt8, p->comm->comm, s))
+          return nccl_fail(p, rc, "ncclAllGather");
+        break;
+      case MG_PLAN_ALLREDUCE_F64:
+        if (int rc = g_rccl.AllReduce(o.p[0], o.p[0], static_cast<size_t>(i[0]), kNcclFloat64, kNcclSum, p->comm->comm, s))
+          return nccl_fail(p, rc, "ncclAllReduce");
+        break;
+      case MG_PLAN_COARSE_BEGIN: {
+        mg_handle* h = static_cast<mg_handle*>(o.p[0]);
+        int rc = mg_set_stream(h, s, 0);
+        if (rc == MG_OK) rc = mg_set_rhs_device(h, o.p[1], i[0], i[1]);
+        if (rc == MG_OK) rc = mg_zero_solution_device(h);
+        if (rc != MG_OK) return plan_fail(&p->err, rc, std::string("coarse begin: ") + mg_last_error(h));
+        break;
+      }
+      case MG_PLAN_COARSE_CYCLE: {
+        mg_handle* h = static_cast<mg_handle*>(o.p[0]);
+        const int rc = mg_cycle(h, i[0]);
+        if (rc != MG_OK) return plan_fail(&p->err, rc, std::string("coarse cycle: ") + mg_last_error(h));
+        break;
+      }
+      case MG_PLAN_COARSE_END: {
+        mg_handle* h = static_cast<mg_handle*>(o.p[0]);
+        const int rc = mg_get_solution_device(h, o.p[1], i[0], i[1]);
+        if (rc != MG_OK) return plan_fail(&p->err, rc, std::string("coarse end: ") + mg_last_error(h));
+        break;
+      }
+      case MG_PLAN_EVENT_RECORD:
+        PLAN_HIP(p, hipEventRecord(p->ev[i[0]], s));
+        break;
+      case MG_PLAN_STREAM_WAIT:
+        PLAN_HIP(p, hipStreamWaitEvent(s, p->ev[i[0]], 0));
+        break;
+      case MG_PLAN_RESULT:
+        result_dev = static_cast<const double*>(o.p[0]);
+        result_stream = s;
+        break;
+      default:
+        return plan_fail(&p->err, MG_ERR_INVALID_VALUE, "unknown plan operation");
+    }
+  }
+  PLAN_HIP(p, hipGetLastError());
+  if (result_dev) {
+    PLAN_HIP(p, hipMemcpyAsync(p->result_host, result_dev, sizeof(double), hipMemcpyDeviceToHost, result_stream));
+    PLAN_HIP(p, hipStreamSynchronize(result_stream));
+    if (result) *result = *p->result_host;
+  }
+  return MG_OK;
+}
+
+}  // extern "C"

@@ -149,6 +149,7 @@ class HipOps:
         self.scratch = torch.zeros(2048, dtype=torch.float64, device=device)          # grown per field shape (_scratch_for)
         self.acc = torch.zeros(1, dtype=torch.float64, device=device)
         self._engine = None
+        self.rec = None                 # dist_plan.PlanRecorder while a cycle is being recorded
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
@@ -203,6 +204,7 @@ class HipOps:
 
     # fused legs (mode "fused"): the single-GPU engine's kernels on the local array with its ghost zone
     supports_overlap = True
+    plan_capable = True               # cycles can be recorded into a native plan (dist_plan.py)
 
     def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff,
                  select=0, inner=None, acoef=None):
@@ -213,17 +215,30 @@ class HipOps:
                                                 rhs_c.stride(0), ci_off, cj_off, hx, hy, omega, coeff, nsweep, int(zero_init), poff,
                                                 None if zero_init else self._p(u), self._p(rhs), self._p(out), self._p(rhs_c),
                                                 self._stream(), int(select), rect, None if acoef is None else self._p(acoef)))
+        if self.rec is not None:
+            clamp = lambda v: max(-(1 << 30), min(1 << 30, int(v)))
+            self.rec.emit(_lib.MG_PLAN_DOWN_LEG,
+                          i=(sm, self._code(rhs), self._code(rhs_c), lnx, lny, rhs.stride(0), lnxc, lnyc, rhs_c.stride(0), ci_off, cj_off,
+                             nsweep, int(zero_init), poff, int(select), int(inner is not None)) + tuple(clamp(v) for v in (inner or (0, 0, 0, 0))),
+                          d=(hx, hy, omega, coeff), p=(None if zero_init else u, rhs, out, rhs_c, acoef))
 
     def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff,
                window=None, acoef=None):
         """out = sweeps(u + P e_c); with `window` = (i_lo, i_hi, j_lo, j_hi) also returns sum r^2 over it (device tensor)."""
         w = window or (0, 0, 0, 0)
+        res = self.torch.empty(1, dtype=self.torch.float64, device=self.device) if window is not None else self.acc
+        self._scratch_for(lnx, lny)
         _lib.check(self.lib.mg_dev_up_leg_var(sm, self._code(u), self._code(e_c), self.comp_dt, lnx, lny, u.stride(0), lnxc, lnyc,
                                               e_c.stride(0), ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, self._p(u),
                                               self._p(rhs), self._p(out), self._p(e_c), int(window is not None), w[0], w[1], w[2],
-                                              w[3], self._scratch_for(lnx, lny), self._p(self.acc), self._stream(),
+                                              w[3], self._p(self.scratch), self._p(res), self._stream(),
                                               None if acoef is None else self._p(acoef)))
-        return self.acc.clone() if window is not None else None
+        if self.rec is not None:
+            self.rec.emit(_lib.MG_PLAN_UP_LEG,
+                          i=(sm, self._code(u), self._code(e_c), self.comp_dt, lnx, lny, u.stride(0), lnxc, lnyc, e_c.stride(0), ci_off,
+                             cj_off, sides, nsweep, poff, int(window is not None)) + tuple(w),
+                          d=(hx, hy, omega, coeff), p=(u, rhs, out, e_c, self.scratch, res, acoef))
+        return res if window is not None else None
 
     def inject_ring(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides, ci_off, cj_off):
         _lib.check(self.lib.mg_dev_inject_ring(self._code(fine), self._code(coarse), lnxf, lnyf, fine.stride(0), lnxc, lnyc,
@@ -256,12 +271,18 @@ class HipOps:
         _lib.check(self.lib.mg_set_stream(e._h, self._stream(), 0))
         _lib.check(self.lib.mg_set_rhs_device(e._h, self._p(rhs_global), rhs_global.stride(0), self._code(rhs_global)))
         _lib.check(self.lib.mg_zero_solution_device(e._h))
+        if self.rec is not None:
+            self.rec.emit(_lib.MG_PLAN_COARSE_BEGIN, i=(rhs_global.stride(0), self._code(rhs_global)), p=(e._h.value, rhs_global))
 
     def coarse_cycle(self):
         self._engine.cycle(1)
+        if self.rec is not None:
+            self.rec.emit(_lib.MG_PLAN_COARSE_CYCLE, i=(1,), p=(self._engine._h.value,))
 
     def coarse_end(self, out_global):
         _lib.check(self.lib.mg_get_solution_device(self._engine._h, self._p(out_global), out_global.stride(0), self._code(out_global)))
+        if self.rec is not None:
+            self.rec.emit(_lib.MG_PLAN_COARSE_END, i=(out_global.stride(0), self._code(out_global)), p=(self._engine._h.value, out_global))
 
     def close(self):
         if self._engine is not None:
@@ -298,8 +319,10 @@ class DistributedMultigrid:
 
     def __init__(self, NX, NY, px, py, ranks, ops, dist=None, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0,
                  max_levels=None, cycle="V", pre=2, post=2, smoother="jacobi", omega=0.8, coarse_tol=1e-12,
-                 coarse_maxit=1000, agglomerate_at=1025, mode="auto", overlap=True):
-        """Precision: every level in ops.np_dtype, or -- with an `ops` built for per-level mixed precision (ops.mixed:
+                 coarse_maxit=1000, agglomerate_at=1025, mode="auto", overlap=True, native="auto"):
+        """native: replay the cycle from a recorded plan (dist_plan.py; one C call per cycle).  "auto": whenever the
+        kernels are the device ones, the mode is "fused" and the ranks talk over RCCL (or live in this process).
+        Precision: every level in ops.np_dtype, or -- with an `ops` built for per-level mixed precision (ops.mixed:
         PrecisionManager('mixed'), core/precision.py:337-357) -- level l >= L // 2 in fp32 and the rest, like the
         coarsest level, in fp64, decomposed and replicated levels alike."""
         from .facade import default_max_levels
@@ -372,6 +395,44 @@ class DistributedMultigrid:
             torch = self.torch
             self._comm_stream = torch.cuda.Stream()
             self._ev_a, self._ev_b = torch.cuda.Event(), torch.cuda.Event()
+        # native replay of the cycle (dist_plan.py)
+        plan_ok = (self.mode == "fused" and getattr(ops, "plan_capable", False) and self.Ld > 0 and
+                   (dist is None or dist.get_backend() == "nccl"))
+        if native not in ("auto", True, False):
+            raise ValueError(f"Unknown native setting: {native}")
+        if native is True and not plan_ok:
+            raise ValueError("native cycle plans need the device kernels, mode 'fused' and RCCL (or in-process ranks)")
+        self.native = plan_ok if native == "auto" else bool(native)
+        self.native_required = native is True
+        self.native_failure = None               # why "auto" fell back to the Python driver, if it did
+        self._plan_exchanges = 0
+        self._rec = None                         # PlanRecorder while the first cycle is being recorded
+        self._plan = None
+        self._plan_state = None
+        self._comm = None
+        self._bufs = {}                          # persistent staging buffers (pack / unpack / gather)
+        self._norm_value = None                  # sum of r^2 the last native cycle returned
+        self.native_cycles = 0
+
+    # ---- primitives the plan recorder sees ------------------------------------------------------
+    def _copy(self, dst, src):
+        dst.copy_(src)
+        if self._rec is not None:
+            self._rec.copy2d(dst, src)
+
+    def _buf(self, key, shape, dtype, device, zero=False):
+        """staging buffer that lives as long as the solver (a recorded plan holds its pointer)"""
+        t = self._bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = (self.torch.zeros if zero else self.torch.empty)(tuple(shape), dtype=dtype, device=device)
+            self._bufs[key] = t
+        return t
+
+    def _add(self, a, b):
+        out = a + b
+        if self._rec is not None:
+            self._rec.add(out, a, b)
+        return out
 
     # ---- neighbours ----------------------------------------------------------------------
     def _nbr(self, d, dx, dy):
@@ -384,6 +445,8 @@ class DistributedMultigrid:
         """sends/recvs: lists of (peer_rank, tensor): batched isend/irecv (RCCL send/recv, one group per phase)."""
         if self.dist is None or not (sends or recvs):
             return
+        if self._rec is not None:
+            self._rec.group(sends, recvs)
         if self._stage_p2p is None:
             # gloo moves device tensors with host-side memcpy on their raw pointers, unordered against the HIP streams
             # that produce / consume them (rehearsals on a one-GPU box): stage through host tensors, synchronously.
@@ -431,7 +494,7 @@ class DistributedMultigrid:
                     sends.append((p, t[src]))          # whole padded rows: one contiguous chunk
                     recvs.append((p, t[dst]))
         for dst, src in local:
-            dst.copy_(src)
+            self._copy(dst, src)
         self._p2p(sends, recvs)
         # phase 2: columns (strided: packed into contiguous buffers)
         sends, recvs, local, unpack = [], [], [], []
@@ -448,24 +511,29 @@ class DistributedMultigrid:
                     psrc = slice(pb.oj_hi - G + 1, pb.oj_hi + 1) if dy < 0 else slice(pb.oj_lo, pb.oj_lo + G)
                     local.append((t[:b.lnx, dst], fields[p][:pb.lnx, psrc]))
                 else:
-                    sbuf = t[:b.lnx, src].contiguous()
-                    rbuf = torch.empty_like(sbuf)
+                    sbuf = self._buf(("pack", name, l, r, dy), (b.lnx, G), t.dtype, t.device)
+                    rbuf = self._buf(("unpack", name, l, r, dy), (b.lnx, G), t.dtype, t.device)
+                    self._copy(sbuf, t[:b.lnx, src])
                     sends.append((p, sbuf))
                     recvs.append((p, rbuf))
                     unpack.append((t[:b.lnx, dst], rbuf))
         for dst, src in local:
-            dst.copy_(src)
+            self._copy(dst, src)
         self._p2p(sends, recvs)
         for dst, src in unpack:
-            dst.copy_(src)
+            self._copy(dst, src)
 
     def allreduce_sum(self, parts):
         """parts: {rank: 1-element fp64 tensor}.  Returns the global sum as a Python float."""
         total = None
         for r in self.ranks:
-            total = parts[r] if total is None else total + parts[r]
+            total = parts[r] if total is None else self._add(total, parts[r])
         if self.dist is not None:
             self.dist.all_reduce(total)
+            if self._rec is not None:
+                self._rec.allreduce(total)
+        if self._rec is not None:
+            self._rec.result(total)
         return float(total.item())
 
     # ---- agglomeration -----------------------------------------------------------------------
@@ -477,18 +545,21 @@ class DistributedMultigrid:
         if self.dist is None:
             for r, d in self.doms.items():
                 b = d.blk[La]
-                self.rhs_a[b.gx0 + b.i_lo:b.gx0 + b.i_hi, b.gy0 + b.j_lo:b.gy0 + b.j_hi] = d.rc[b.i_lo:b.i_hi, b.j_lo:b.j_hi]
+                self._copy(self.rhs_a[b.gx0 + b.i_lo:b.gx0 + b.i_hi, b.gy0 + b.j_lo:b.gy0 + b.j_hi], d.rc[b.i_lo:b.i_hi, b.j_lo:b.j_hi])
             return
         (r, d), = self.doms.items()
         b = d.blk[La]
-        mine = torch.zeros((self.gmx, self.gmy), dtype=d.rc.dtype, device=d.rc.device)
-        mine[:b.i_hi - b.i_lo, :b.j_hi - b.j_lo] = d.rc[b.i_lo:b.i_hi, b.j_lo:b.j_hi]
-        parts = [torch.empty_like(mine) for _ in range(self.px * self.py)]
-        self.dist.all_gather(parts, mine)
-        for q, part in enumerate(parts):
+        P = self.px * self.py
+        mine = self._buf(("gather", "mine"), (self.gmx, self.gmy), d.rc.dtype, d.rc.device, zero=True)   # the padding stays zero
+        every = self._buf(("gather", "all"), (P, self.gmx, self.gmy), d.rc.dtype, d.rc.device)
+        self._copy(mine[:b.i_hi - b.i_lo, :b.j_hi - b.j_lo], d.rc[b.i_lo:b.i_hi, b.j_lo:b.j_hi])
+        self.dist.all_gather(list(every.unbind(0)), mine)
+        if self._rec is not None:
+            self._rec.allgather(mine, every)
+        for q in range(P):
             qb = Block(NXa, NYa, self.px, self.py, *divmod(q, self.py), self.G)
-            self.rhs_a[qb.gx0 + qb.i_lo:qb.gx0 + qb.i_hi, qb.gy0 + qb.j_lo:qb.gy0 + qb.j_hi] = \
-                part[:qb.i_hi - qb.i_lo, :qb.j_hi - qb.j_lo]
+            self._copy(self.rhs_a[qb.gx0 + qb.i_lo:qb.gx0 + qb.i_hi, qb.gy0 + qb.j_lo:qb.gy0 + qb.j_hi],
+                       every[q, :qb.i_hi - qb.i_lo, :qb.j_hi - qb.j_lo])
 
     def _replicated_cycle(self, l):
         """Coarse tail: gather the coarse rhs, run the remaining levels on the single-GPU engine (on every GPU),
@@ -500,7 +571,7 @@ class DistributedMultigrid:
         self.ops.coarse_end(self.e_a)
         for d in self.doms.values():
             bc = d.blk[l + 1]
-            d.ec[:bc.lnx, :bc.lny] = self.e_a[bc.gx0:bc.gx0 + bc.lnx, bc.gy0:bc.gy0 + bc.lny]
+            self._copy(d.ec[:bc.lnx, :bc.lny], self.e_a[bc.gx0:bc.gx0 + bc.lnx, bc.gy0:bc.gy0 + bc.lny])
 
     # ---- the cycle (solvers/multigrid.py:253-337) ------------------------------------------------
     def _reps(self, l):
@@ -531,9 +602,75 @@ class DistributedMultigrid:
         if self.Ld == 0:                      # nothing distributed: the replicated engine is the whole solver
             raise RuntimeError("single-block problems go through MultigridEngine")
         self._last_norm_parts = None
+        self._norm_value = None
+        if self.native and l == 0 and not zero_u:
+            return self._cycle_native()
         if self.mode == "fused":
             return self._cycle_fused(l, zero_u)
         return self._cycle_per_operator(l)
+
+    # ---- native replay (dist_plan.py) --------------------------------------------------------------
+    def _pointer_state(self):
+        return tuple((d.u[l].data_ptr(), d.t[l].data_ptr(), d.rhs[l].data_ptr(), 0 if d.a[l] is None else d.a[l].data_ptr())
+                     for d in self.doms.values() for l in range(self.Ld)) + \
+            tuple(0 if d.ring_sumsq is None else d.ring_sumsq.data_ptr() for d in self.doms.values()) + (self.var,)
+
+    def _drop_plan(self):
+        if self._plan is not None:
+            self.torch.cuda.synchronize()
+            self._plan.close()
+        self._plan = None
+        self._plan_state = None
+
+    def _cycle_native(self):
+        """The first cycle (and the first after anything moved a field to another buffer) runs through the Python driver
+        with a recorder attached; every other one is a single mg_plan_run.  Either way the sum of r^2 over the grid comes
+        back with the cycle (the eager path computes it lazily in residual_norm())."""
+        from . import dist_plan
+        torch = self.torch
+        state = self._pointer_state()
+        if self._plan is not None and self._plan_state != state:
+            self._drop_plan()
+        if self._plan is None:
+            device = next(iter(self.doms.values())).u[0].device
+            before = self.exchanges
+            self._rec = self.ops.rec = dist_plan.PlanRecorder()
+            try:
+                self._cycle_fused(0, False)
+                self._norm_value = self.allreduce_sum(self._last_norm_parts)
+                rec = self._rec
+            finally:
+                self._rec = self.ops.rec = None
+            self._last_norm_parts = None
+            self._plan_exchanges = self.exchanges - before
+            if self._pointer_state() != state:
+                raise RuntimeError("a cycle must leave every field in the buffer it started in")
+            # the plan (and, between processes, the library's own RCCL communicator); a rank that cannot build one takes
+            # every rank back to the Python driver -- agreed on through torch.distributed, so nobody replays alone
+            failure = None
+            try:
+                if self.dist is not None and self._comm is None:
+                    self._comm = dist_plan.shared_comm(self.dist, device.index or 0)
+                self._plan = dist_plan.CyclePlan(rec, self._comm, device.index or 0)
+                self._plan_state = state
+            except Exception as exc:
+                failure = exc
+            if self.dist is not None:
+                flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device=device)
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+                if int(flag.item()) and failure is None:
+                    failure = RuntimeError("another rank could not build its cycle plan")
+            if failure is not None:
+                if self.native_required:
+                    raise failure
+                self._drop_plan()
+                self.native = False
+                self.native_failure = repr(failure)
+            return
+        comm = self._comm_stream.cuda_stream if self.overlap else torch.cuda.current_stream().cuda_stream
+        self._norm_value = self._plan.run(torch.cuda.current_stream().cuda_stream, comm)
+        self.native_cycles += 1
+        self.exchanges += self._plan_exchanges
 
     def _cycle_fused(self, l, zero_u, first_visit_rhs=False):
         """Two launches and (at most) two exchanges per level.  Validity bookkeeping (m = cells of the ghost zone that
@@ -570,14 +707,24 @@ class DistributedMultigrid:
             # tiles that read no ghost data run on the compute stream while the exchange runs on the comm stream
             torch = self.torch
             compute = torch.cuda.current_stream()
+            rec = self._rec
             self._ev_a.record(compute)
+            if rec is not None:
+                rec.event_record(0)
+                rec.stream = 1
+                rec.stream_wait(0)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(self._ev_a)
                 for name in pending:
                     self.exchange(name, l)
                 self._ev_b.record(self._comm_stream)
+            if rec is not None:
+                rec.event_record(1)
+                rec.stream = 0
             down(1, inner_rect)
             compute.wait_event(self._ev_b)
+            if rec is not None:
+                rec.stream_wait(1)
             down(2, inner_rect)
         else:
             for name in pending:
@@ -602,7 +749,7 @@ class DistributedMultigrid:
                                   self.omega, self.coeff, self.post, (b.gx0 + b.gy0) & 1, win, **kw)
             d.u[l], d.t[l] = d.t[l], d.u[l]
             if want_norm:
-                parts[r] = res + d.ring_sumsq
+                parts[r] = self._add(res, d.ring_sumsq)
         if want_norm:
             self._last_norm_parts = parts
 
@@ -661,6 +808,7 @@ class DistributedMultigrid:
         self.ops.coarse_coefficient(np.ascontiguousarray(a_at(np.arange(NXa) << self.Ld, np.arange(NYa) << self.Ld), dtype=np.float64))
         self.var = True
         self._last_norm_parts = None
+        self._norm_value = None
 
     def set_problem(self, rhs_of_block, u0_of_block=None):
         """rhs_of_block(block) -> (lnx, lny) array of f on that block (ghost zone and boundary included)."""
@@ -690,11 +838,17 @@ class DistributedMultigrid:
                     ring = ring + self.ops.sumsq(d.rhs[0], max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), 0, 1)
                 if b.sides & SIDE_JHI:
                     ring = ring + self.ops.sumsq(d.rhs[0], max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), b.lny - 1, b.lny)
-                d.ring_sumsq = ring
+                if d.ring_sumsq is None:
+                    d.ring_sumsq = ring
+                else:
+                    d.ring_sumsq.copy_(ring)           # same buffer: a recorded plan holds its pointer
         self._last_norm_parts = None
+        self._norm_value = None
 
     def residual_norm(self):
         hx, hy = self.h[0]
+        if self._norm_value is not None:            # a native cycle brought the sum back with it
+            return math.sqrt(hx * hy * self._norm_value)
         if self._last_norm_parts is not None:       # the up leg of the last cycle already summed r^2 over the owned cells
             return math.sqrt(hx * hy * self.allreduce_sum(self._last_norm_parts))
         if self.mode == "fused":
@@ -732,6 +886,7 @@ class DistributedMultigrid:
             if d.t[0] is not None:
                 d.t[0].copy_(d.u[0])
         self._last_norm_parts = None
+        self._norm_value = None
 
     def local_solution(self, rank):
         d = self.doms[rank]
@@ -739,6 +894,8 @@ class DistributedMultigrid:
         return b, d.u[0][:b.lnx, :b.lny].cpu().numpy()
 
     def close(self):
+        self._drop_plan()
+        self._comm = None                        # shared per process: dist_plan.shutdown() destroys it
         self.ops.close()
 
 
@@ -835,9 +992,12 @@ def bench_main(args, rank, local_rank, world):
         providers = (("f32", factory(np.float32)), ("f64", factory(np.float64)))
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     solvers = {}
+    # MG_DIST_NATIVE=0: the Python driver every cycle (default: recorded cycle plans wherever they apply)
+    native = "auto" if os.environ.get("MG_DIST_NATIVE", "1") != "0" else False
     for name, ops in providers:
         solvers[name] = DistributedMultigrid(NX, NY, px, py, [rank], ops, dist, domain=domain, smoother="jacobi", omega=0.8,
-                                             cycle="V", pre=2, post=2, agglomerate_at=getattr(args, "agglomerate_at", 1025))
+                                             cycle="V", pre=2, post=2, agglomerate_at=getattr(args, "agglomerate_at", 1025),
+                                             native=native)
 
     def reset():
         for sv in solvers.values():
@@ -943,11 +1103,20 @@ def bench_main(args, rank, local_rank, world):
                                  "included) / launch time; unfused_equivalent_* prices the same work as one launch per operator "
                                  "(SURVEY 8d)"},
             "exchanges_per_cycle": exchanges,
+            "driver": {"native_plan_cycles": sum(x.native_cycles for x in solvers.values()),
+                       "python_cycles": W + len(long_hist) - sum(x.native_cycles for x in solvers.values()),
+                       "fallback": next((x.native_failure for x in solvers.values() if x.native_failure), None)},
             "note": "distributed levels: communication-avoiding fused legs (two launches and about one halo exchange per "
-                    "level and cycle, orchestrated from Python over torch.distributed P2P); the replicated coarse "
-                    "hierarchy runs on the fused single-GPU engine; same precision policy as the N = 1 line",
+                    "level and cycle); a cycle is recorded once through the Python driver and then replayed from C++ -- one "
+                    "mg_plan_run per cycle enqueues the kernels, the RCCL send/recv groups, the coarse all-gather and the "
+                    "norm all-reduce on two HIP streams (MG_DIST_NATIVE=0: torch.distributed P2P from Python every cycle); "
+                    "the replicated coarse hierarchy runs on the fused single-GPU engine; same precision policy as the "
+                    "N = 1 line",
         }), flush=True)
     for x in solvers.values():
         x.close()
+    if on_gpu:
+        from . import dist_plan
+        dist_plan.shutdown()
     dist.destroy_process_group()
     return 0

@@ -141,6 +141,36 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _plans_mirror_each_other(sigs):
+    """sigs[p] = PlanRecorder.signature() of rank p.  Same number and kinds of communication steps on every rank, equal
+    collective sizes, and inside p2p group k every send p -> q (n bytes) has exactly one receive on q from p of n bytes."""
+    world = len(sigs)
+    if len({len(s) for s in sigs}) != 1 or len(sigs[0]) == 0:
+        return False
+    for k in range(len(sigs[0])):
+        kinds = {s[k][0] for s in sigs}
+        if len(kinds) != 1:
+            return False
+        if kinds != {"p2p"}:
+            if len({s[k][1] for s in sigs}) != 1:
+                return False
+            continue
+        sends = sorted((p, peer, n) for p in range(world) for kind, peer, n in sigs[p][k][1] if kind == "send")
+        recvs = sorted((peer, p, n) for p in range(world) for kind, peer, n in sigs[p][k][1] if kind == "recv")
+        if sends != recvs or not sends or len(set((a, b) for a, b, _ in sends)) != len(sends):
+            return False
+    return True
+
+
+def test_plan_signature_checker_rejects_mismatches():
+    ok = [[("p2p", (("send", 1, 8), ("recv", 1, 8))), ("allreduce", 1)], [("p2p", (("send", 0, 8), ("recv", 0, 8))), ("allreduce", 1)]]
+    assert _plans_mirror_each_other(ok)
+    bad_size = [ok[0], [("p2p", (("send", 0, 8), ("recv", 0, 16))), ("allreduce", 1)]]
+    missing = [ok[0], [("p2p", (("send", 0, 8),)), ("allreduce", 1)]]
+    shifted = [ok[0], [("allreduce", 1), ("p2p", (("send", 0, 8), ("recv", 0, 8)))]]
+    assert not _plans_mirror_each_other(bad_size) and not _plans_mirror_each_other(missing) and not _plans_mirror_each_other(shifted)
+
+
 def _worker(rank, world, port, px, py, cyc, kind, omega, out_path, mode="per_operator"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -153,11 +183,26 @@ def _worker(rank, world, port, px, py, cyc, kind, omega, out_path, mode="per_ope
     b, u = s.local_solution(rank)
     gathered = [None] * world
     dist.all_gather_object(gathered, (b.gx0, b.gy0, b.i_lo, b.i_hi, b.j_lo, b.j_hi, u))
+    plan_ok = True
+    if mode == "fused":
+        # what a native cycle plan of this rank would hand to RCCL (dist_plan.PlanRecorder): one more cycle with the
+        # recorder attached; every rank's communication groups must mirror its peers', group by group
+        from mixed_precision_multigrid_solvers_for_pdes_amd import dist_plan
+        s._rec = dist_plan.PlanRecorder()
+        s._last_norm_parts = None
+        s._cycle_fused(0, False)
+        s.allreduce_sum(s._last_norm_parts)
+        sig = s._rec.signature()
+        s._rec = None
+        sigs = [None] * world
+        dist.all_gather_object(sigs, sig)
+        if rank == 0:
+            plan_ok = _plans_mirror_each_other(sigs)
     if rank == 0:
         full = np.full((NX, NY), np.nan)
         for gx0, gy0, i_lo, i_hi, j_lo, j_hi, ul in gathered:
             full[gx0 + i_lo:gx0 + i_hi, gy0 + j_lo:gy0 + j_hi] = ul[i_lo:i_hi, j_lo:j_hi]
-        np.savez(out_path, u=full, hist=np.array(hist))
+        np.savez(out_path, u=full, hist=np.array(hist), plan_ok=plan_ok)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -185,6 +230,7 @@ def test_gloo_multiprocess_fused_mode(tmp_path, world, cyc):
     u_ref, h_ref = _oracle(129, 129, 5, cyc, "jacobi", 0.8, 3)
     np.testing.assert_array_equal(res["u"], u_ref)
     np.testing.assert_allclose(res["hist"], h_ref, rtol=1e-13)
+    assert bool(res["plan_ok"])            # the RCCL steps a native plan would replay pair up across the ranks
 
 
 def test_precision_switch_between_two_decomposed_solvers():
@@ -369,11 +415,26 @@ def _var_worker(rank, world, port, px, py, out_path):
     b, u = s.local_solution(rank)
     gathered = [None] * world
     dist.all_gather_object(gathered, (b.gx0, b.gy0, b.i_lo, b.i_hi, b.j_lo, b.j_hi, u))
+    plan_ok = True
+    if mode == "fused":
+        # what a native cycle plan of this rank would hand to RCCL (dist_plan.PlanRecorder): one more cycle with the
+        # recorder attached; every rank's communication groups must mirror its peers', group by group
+        from mixed_precision_multigrid_solvers_for_pdes_amd import dist_plan
+        s._rec = dist_plan.PlanRecorder()
+        s._last_norm_parts = None
+        s._cycle_fused(0, False)
+        s.allreduce_sum(s._last_norm_parts)
+        sig = s._rec.signature()
+        s._rec = None
+        sigs = [None] * world
+        dist.all_gather_object(sigs, sig)
+        if rank == 0:
+            plan_ok = _plans_mirror_each_other(sigs)
     if rank == 0:
         full = np.full((NX, NY), np.nan)
         for gx0, gy0, i_lo, i_hi, j_lo, j_hi, ul in gathered:
             full[gx0 + i_lo:gx0 + i_hi, gy0 + j_lo:gy0 + j_hi] = ul[i_lo:i_hi, j_lo:j_hi]
-        np.savez(out_path, u=full, hist=np.array(hist))
+        np.savez(out_path, u=full, hist=np.array(hist), plan_ok=plan_ok)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -175,3 +175,65 @@ def test_config5_as_specified_virtual_ranks():
     assert ref_hist[1] < ref_hist[0]
     np.testing.assert_allclose(hist, ref_hist, rtol=1e-12)
     assert np.array_equal(u, u_ref)
+
+
+@pytest.mark.parametrize("px,py,NX,NY,agg,levels,cyc,kind,omega,dtype,var,overlap", [
+    (2, 2, 1025, 1025, 129, None, "V", "jacobi", 0.8, np.float64, False, True),
+    (4, 2, 1025, 513, 129, None, "W", "jacobi", 0.8, np.float32, False, True),
+    (2, 1, 513, 513, 65, None, "V", "rbgs", 1.0, np.float64, False, False),
+    (1, 2, 513, 1025, 129, None, "W", "rbgs", 1.15, "managed32", False, True),
+    (2, 2, 1025, 1025, 257, None, "V", "jacobi", 0.8, "mixed", True, True),
+    (2, 2, 513, 513, 129, 5, "F", "jacobi", 2 / 3, np.float64, True, True),    # F: 2^(L-l-2) visits per level -- few levels
+])
+def test_native_cycle_plan_equals_python_driver(px, py, NX, NY, agg, levels, cyc, kind, omega, dtype, var, overlap):
+    """dist_plan: the cycle recorded once and replayed by mg_plan_run (kernels, halo copies, gather, replicated engine, norm,
+    stream dependencies) against the Python driver issuing the same cycle -- iterate and norms bit for bit; a new
+    right-hand side or new coefficient values (same arrays) reuse the plan."""
+    import torch
+    mixed, managed = dtype == "mixed", dtype == "managed32"
+    fdt = np.float64 if mixed else (np.float32 if managed else dtype)
+    rng = np.random.default_rng(7)
+    rhs = rng.standard_normal((NX, NY)).astype(fdt)
+    rhs2 = rng.standard_normal((NX, NY)).astype(fdt)
+    u0 = rng.standard_normal((NX, NY)).astype(fdt)
+    a_at = _a_at(NX, NY) if var else None
+    out = {}
+    for native in (False, True):
+        ops = D.HipOps(fdt, torch.device("cuda", 0), managed_single=managed, mixed=mixed)
+        s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, max_levels=levels, cycle=cyc, smoother=kind,
+                                   omega=omega, agglomerate_at=agg, overlap=overlap, native=native)
+        assert s.native == native and s.Ld >= 1
+        if var:
+            s.set_coefficient(a_at)
+        hist = []
+        s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+        for _ in range(4):
+            s.cycle(0); hist.append(s.residual_norm())
+        first = H.assemble(s, NX, NY, fdt)
+        if native:
+            assert s.native_cycles == 3 and s._plan is not None and s._plan.n > 10
+        s.set_problem(lambda b: rhs2[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+        hist.append(s.residual_norm())
+        for _ in range(2):
+            s.cycle(0); hist.append(s.residual_norm())
+        if native:
+            assert s.native_cycles == 5                      # same buffers: the recorded plan still applies
+        if var:
+            s.set_coefficient(lambda ix, iy: 1.0 + 0.0 * a_at(ix, iy))
+            s.cycle(0); hist.append(s.residual_norm())
+            s.cycle(0); hist.append(s.residual_norm())
+            if native:
+                assert s.native_cycles == 7                  # new values in the same arrays: still the same plan
+        out[native] = (hist, first, H.assemble(s, NX, NY, fdt))
+        s.close()
+    assert out[True][0] == out[False][0]
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    np.testing.assert_array_equal(out[True][2], out[False][2])
+
+
+def test_rccl_binding_single_rank_plan():
+    """mg_comm_init + a plan with an all-reduce, an all-gather and a send/recv-to-self group on a one-rank communicator
+    (tools/plan_probe.py rccl), in a child process under a timeout: the RCCL calls the multi-GPU plans replay."""
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "plan_probe.py"), "rccl"], capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0 and "RCCL_SELFTEST_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
