@@ -803,11 +803,96 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
   return sweeps;
 }
 
+// The same solve with as few instructions per time step as the arithmetic allows -- ONE wave issues an instruction every
+// ~5 cycles whatever it is, so lexgs_pipelined_5x5's ~270 instructions per sweep (per-lane time counters, ring / neighbour
+// selects, both division variants, a three-deep history shifted on every update) are what its ~1350 cycles per sweep are
+// made of.  Requirements: the ring of the iterate is zero (every coarsest problem below the top of a hierarchy is a
+// correction equation with homogeneous boundary values).  Then the nine unknowns sit in a 4-wide lane grid (lane = 4 ci +
+// cj, cj < 3) whose pad lanes hold 0.0, all four neighbours are plain DPP row shifts by 1 and 4 with bound_ctrl zeros
+// standing in for the ring, the anti-diagonal parity classes update under two constant lane masks on alternating time
+// steps (three masked start-up steps), and the snapshot the stop test needs is the current value, the previous one or the
+// one before, by a per-lane constant.  Same expressions in the same order as lexgs_pipelined_5x5 (sums with an exact zero
+// instead of a selected ring value), same sweep count; the nine squares of the stop test are added in another lane order.
+template <typename T, bool VAR, bool EXACT>
+__device__ int lexgs_5x5_zero_ring(T* __restrict__ su, const T* __restrict__ sf, T hx2, T hy2, T diag, T coeff, T omega, T one_m_omega,
+                                   double hxhy, double tol_x, int maxit, int lane, const T* __restrict__ sa, T sigma) {
+  constexpr int ny = 5;
+  const T rhx2 = T(1) / hx2, rhy2 = T(1) / hy2, rdiag = T(1) / diag;
+  double ring = 0.0;
+  if (lane < 25) {
+    const int i = lane / ny, j = lane - i * ny;
+    if (i == 0 || i == 4 || j == 0 || j == 4) ring = (double)sf[lane] * (double)sf[lane];
+  }
+  ring = wave_first(wave_reduce_sum(ring));
+  const int ci = lane >> 2, cj = lane & 3;
+  const bool mine = lane < 11 && cj < 3;
+  const int g = mine ? (ci + 1) * ny + cj + 1 : ny + 1, d = ci + cj + 2;
+  const T fv = mine ? sf[g] : T(0);
+  T uv = mine ? su[g] : T(0);
+  T aip = T(1), aim = T(1), ajp = T(1), ajm = T(1), Dv = diag;
+  if (VAR) {
+    const T ac = sa[g];
+    aip = T(0.5) * (ac + sa[g + ny]); aim = T(0.5) * (ac + sa[g - ny]); ajp = T(0.5) * (ac + sa[g + 1]); ajm = T(0.5) * (ac + sa[g - 1]);
+    Dv = (EXACT ? (aip + aim) * rhx2 + (ajp + ajm) * rhy2 : (aip + aim) / hx2 + (ajp + ajm) / hy2) + sigma;
+  }
+  const bool even = mine && !(d & 1), odd = mine && (d & 1);
+  const bool lead1 = mine && (d == 3 || d == 4), lead2 = mine && d == 2;   // sweeps ahead of the sweep under test
+  T h1 = uv, h2 = uv;                                                      // the lane's previous two sweep values
+  auto step = [&](bool upd) {
+    const T up = dpp_row_move<0x114>(uv), dn = dpp_row_move<0x104>(uv);    // row_shr:4 / row_shl:4: lanes c -+ 4
+    const T lf = dpp_row_move<0x111>(uv), rt = dpp_row_move<0x101>(uv);
+    const T sx = VAR ? aip * dn + aim * up : dn + up, sy = VAR ? ajp * rt + ajm * lf : rt + lf;
+    const T nb = EXACT ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
+    const T num = fv + nb;
+    const T un = VAR ? num / Dv : (EXACT ? num * rdiag : num / diag);
+    const T nv = one_m_omega * uv + omega * un;
+    h2 = upd ? h1 : h2;
+    h1 = upd ? uv : h1;
+    uv = upd ? nv : uv;
+  };
+  // cell on anti-diagonal d takes its sweep-k value at time 2k + d: t = 4, 5, 6 start the pipeline, from t = 7 on every
+  // odd (even) time step updates all odd (even) anti-diagonals
+  step(mine && d == 2);
+  step(mine && d == 3);
+  step(mine && (d == 2 || d == 4));
+  int sweeps = maxit;
+  T result = uv;
+  for (int k = 1;; ++k) {
+    step(odd);
+    step(even);                                    // t = 2k + 6: the last cell has its sweep-k value
+    const T snap = lead2 ? h2 : (lead1 ? h1 : uv);
+    const T up = dpp_row_move<0x114>(snap), dn = dpp_row_move<0x104>(snap);
+    const T lf = dpp_row_move<0x111>(snap), rt = dpp_row_move<0x101>(snap);
+    const T sx = VAR ? aip * dn + aim * up : dn + up, sy = VAR ? ajp * rt + ajm * lf : rt + lf;
+    const T rv = fv - coeff * ((EXACT ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap * (VAR ? Dv : diag));
+    double acc = mine ? (double)rv * (double)rv : 0.0;
+    acc = wave_first(row0_reduce_sum(acc));
+    if (hxhy * (acc + ring) < tol_x || k >= maxit) {
+      result = snap;
+      sweeps = k;
+      break;
+    }
+  }
+  if (mine) su[g] = result;
+  wave_lds_fence<T>();
+  return sweeps;
+}
+
 template <typename T, bool VAR = false>
 __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* __restrict__ hist, int nx, int ny,
                                T hx2, T hy2, T diag, T coeff, T omega, T one_m_omega, bool exact, double hxhy,
                                double tol_x, int maxit, int lane, const T* __restrict__ sa = nullptr, T sigma = T(0)) {
-  if (nx == 5 && ny == 5) return lexgs_pipelined_5x5<T, VAR>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, exact, hxhy, tol_x, maxit, lane, sa, sigma);
+  if (nx == 5 && ny == 5) {
+    bool ring_nonzero = false;
+    if (lane < 25) {
+      const int i = lane / 5, j = lane - i * 5;
+      ring_nonzero = (i == 0 || i == 4 || j == 0 || j == 4) && su[lane] != T(0);
+    }
+    if (__ballot(ring_nonzero) == 0ull)
+      return exact ? lexgs_5x5_zero_ring<T, VAR, true>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, hxhy, tol_x, maxit, lane, sa, sigma)
+                   : lexgs_5x5_zero_ring<T, VAR, false>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, hxhy, tol_x, maxit, lane, sa, sigma);
+    return lexgs_pipelined_5x5<T, VAR>(su, sf, hx2, hy2, diag, coeff, omega, one_m_omega, exact, hxhy, tol_x, maxit, lane, sa, sigma);
+  }
   // face means and diagonal of cell c (variable coefficient; coarse_lexgs_kernel's expressions)
   auto faces = [&](int c, T& aip, T& aim, T& ajp, T& ajm, T& Dv) {
     const T ac = sa[c];
