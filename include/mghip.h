@@ -320,6 +320,8 @@ int mg_plan_create(const mg_plan_op* ops, int n_ops, void* comm, int device, mg_
 /* enqueue every operation; when the plan has a RESULT, wait for it and store it in *result */
 int mg_plan_run(mg_plan* plan, void* compute_stream, void* comm_stream, double* result);
 int mg_plan_num_ops(const mg_plan* plan, int* n);
+/* COPY2D operations of the plan and the launches they run as (runs of independent copies share one launch) */
+int mg_plan_copy_launches(const mg_plan* plan, int* n_copies, int* n_launches);
 const char* mg_plan_error(const mg_plan* plan);   /* NULL plan: the last mg_comm_* / mg_plan_create error of this thread */
 int mg_plan_destroy(mg_plan* plan);
 /* RCCL through the library the process already uses (`rccl_library`: path of librccl.so, e.g. torch's own copy).

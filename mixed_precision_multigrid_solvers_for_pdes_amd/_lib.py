@@ -114,6 +114,7 @@ SIGNATURES = {
     "mg_plan_create": (_i, [C.POINTER(MgPlanOp), _i, _vp, _i, C.POINTER(_vp)]),
     "mg_plan_run": (_i, [_vp, _vp, _vp, _pd]),
     "mg_plan_num_ops": (_i, [_vp, _pi]),
+    "mg_plan_copy_launches": (_i, [_vp, _pi, _pi]),
     "mg_plan_error": (C.c_char_p, [_vp]),
     "mg_plan_destroy": (_i, [_vp]),
     "mg_comm_unique_id": (_i, [C.c_char_p, _vp]),

@@ -73,20 +73,33 @@ struct Comm {
 };
 
 // ---- device helpers --------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) copy2d_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int rows,
-                                                     int width_words, int64_t dst_pitch_words, int64_t src_pitch_words) {
-  const int r = blockIdx.y;
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < width_words; c += gridDim.x * 256)
-    dst[r * dst_pitch_words + c] = src[r * src_pitch_words + c];
-  (void)rows;
-}
-
 __global__ void add_f64_kernel(double* dst, const double* a, const double* b) { *dst = b ? *a + *b : *a; }
+
+// Up to kBatch independent 2-D copies in one launch (blockIdx.z = copy): halo packing / unpacking and the scatter of the
+// gathered coarse blocks are runs of small copies; one launch per run instead of one per copy.
+constexpr int kBatch = 8;
+struct CopyBatch {
+  uint32_t* dst[kBatch];
+  const uint32_t* src[kBatch];
+  int rows[kBatch], words[kBatch];
+  int64_t dpitch[kBatch], spitch[kBatch];
+  int n, max_rows, max_words;
+};
+__global__ void __launch_bounds__(256) copy2d_batch_kernel(CopyBatch b) {
+  const int k = blockIdx.z, r = blockIdx.y;
+  if (r >= b.rows[k]) return;
+  uint32_t* __restrict__ d = b.dst[k] + r * b.dpitch[k];
+  const uint32_t* __restrict__ s = b.src[k] + r * b.spitch[k];
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < b.words[k]; c += gridDim.x * 256) d[c] = s[c];
+}
 
 }  // namespace
 
 struct mg_plan {
   std::vector<mg_plan_op> ops;
+  std::vector<int> batch_of;            // per op: -1, or the index into `batches` the op starts (members that follow are skipped)
+  std::vector<CopyBatch> batches;
+  std::vector<int> batch_len;
   Comm* comm = nullptr;
   int device = 0;
   hipEvent_t ev[8] = {};
@@ -153,6 +166,59 @@ int check_op(const mg_plan_op& o, int idx, std::string* err) {
       return o.p[0] ? MG_OK : bad("result: NULL pointer");
     default:
       return bad("unknown operation");
+  }
+}
+
+// Runs of consecutive COPY2D operations on one stream whose regions do not touch (bounding byte ranges: a copy that reads what
+// an earlier one of the run writes -- the column phase of a halo exchange after the row phase -- starts a new run).
+void build_batches(mg_plan* p) {
+  const int n = static_cast<int>(p->ops.size());
+  p->batch_of.assign(n, -1);
+  struct Region { uintptr_t lo, hi; int width, pitch; };
+  auto region = [](const void* ptr, int rows, int width, int pitch) {
+    Region r;
+    r.lo = reinterpret_cast<uintptr_t>(ptr);
+    r.hi = r.lo + (rows > 0 ? static_cast<uintptr_t>(rows - 1) * pitch + width : 0);
+    r.width = width; r.pitch = pitch;
+    return r;
+  };
+  // disjoint byte ranges, or -- same pitch -- disjoint column bands (the two ghost columns of one array)
+  auto touch = [](const Region& a, const Region& b) {
+    if (!(a.lo < b.hi && b.lo < a.hi)) return false;
+    if (a.pitch == b.pitch && a.pitch > 0) {
+      const uintptr_t P = static_cast<uintptr_t>(a.pitch), ca = a.lo % P, cb = b.lo % P;
+      if (ca + a.width <= P && cb + b.width <= P && (ca + a.width <= cb || cb + b.width <= ca)) return false;
+    }
+    return true;
+  };
+  int k = 0;
+  while (k < n) {
+    if (p->ops[k].op != MG_PLAN_COPY2D) { ++k; continue; }
+    CopyBatch b{};
+    std::vector<Region> writes, reads;
+    int m = k;
+    while (m < n && b.n < kBatch && p->ops[m].op == MG_PLAN_COPY2D && p->ops[m].stream == p->ops[k].stream) {
+      const mg_plan_op& o = p->ops[m];
+      const Region d = region(o.p[0], o.i[0], o.i[1], o.i[2]), sr = region(o.p[1], o.i[0], o.i[1], o.i[3]);
+      bool clash = false;
+      for (auto& w : writes) clash = clash || touch(sr, w) || touch(d, w);
+      for (auto& r : reads) clash = clash || touch(d, r);
+      if (clash) break;
+      if (o.i[0] > 0 && o.i[1] > 0) {
+        const int j = b.n++;
+        b.dst[j] = static_cast<uint32_t*>(o.p[0]); b.src[j] = static_cast<const uint32_t*>(o.p[1]);
+        b.rows[j] = o.i[0]; b.words[j] = o.i[1] / 4; b.dpitch[j] = o.i[2] / 4; b.spitch[j] = o.i[3] / 4;
+        b.max_rows = b.max_rows > o.i[0] ? b.max_rows : o.i[0];
+        b.max_words = b.max_words > o.i[1] / 4 ? b.max_words : o.i[1] / 4;
+        writes.push_back(d);
+        reads.push_back(sr);
+      }
+      ++m;
+    }
+    p->batch_of[k] = static_cast<int>(p->batches.size());
+    p->batches.push_back(b);
+    p->batch_len.push_back(m - k);
+    k = m;
   }
 }
 
@@ -224,6 +290,7 @@ int mg_plan_create(const mg_plan_op* ops, int n_ops, void* comm, int device, mg_
   p->ops.assign(ops, ops + n_ops);
   p->comm = static_cast<Comm*>(comm);
   p->device = device;
+  build_batches(p);
   for (auto& ev : p->ev) {
     e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
@@ -237,6 +304,16 @@ int mg_plan_create(const mg_plan_op* ops, int n_ops, void* comm, int device, mg_
 int mg_plan_num_ops(const mg_plan* plan, int* n) {
   if (!plan || !n) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_num_ops: NULL argument");
   *n = static_cast<int>(plan->ops.size());
+  return MG_OK;
+}
+
+int mg_plan_copy_launches(const mg_plan* plan, int* n_copies, int* n_launches) {
+  if (!plan || !n_copies || !n_launches) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_copy_launches: NULL argument");
+  int copies = 0, launches = 0;
+  for (const auto& o : plan->ops) copies += (o.op == MG_PLAN_COPY2D);
+  for (const auto& b : plan->batches) launches += (b.n > 0);
+  *n_copies = copies;
+  *n_launches = launches;
   return MG_OK;
 }
 
@@ -279,12 +356,14 @@ int mg_plan_run(mg_plan* p, void* compute_stream, void* comm_stream, double* res
         break;
       }
       case MG_PLAN_COPY2D: {
-        if (i[0] == 0 || i[1] == 0) break;
-        const int words = i[1] / 4;
-        int gx = (words + 255) / 256;
-        if (gx > 64) gx = 64;
-        copy2d_kernel<<<dim3(gx, i[0]), 256, 0, s>>>(static_cast<uint32_t*>(o.p[0]), static_cast<const uint32_t*>(o.p[1]), i[0], words,
-                                                     i[2] / 4, i[3] / 4);
+        const int bi = p->batch_of[k];                    // every run of copies starts with its batch
+        const CopyBatch& b = p->batches[bi];
+        if (b.n > 0) {
+          int gx = (b.max_words + 255) / 256;
+          if (gx > 64) gx = 64;
+          copy2d_batch_kernel<<<dim3(gx, b.max_rows, b.n), 256, 0, s>>>(b);
+        }
+        k += p->batch_len[bi] - 1;
         break;
       }
       case MG_PLAN_ADD_F64:

@@ -187,6 +187,12 @@ class CyclePlan:
             _lib.check_plan(rc, self.handle)
         return out.value if self.has_result else None
 
+    def copy_launches(self):
+        """(COPY2D operations, launches they run as)"""
+        a, b = C.c_int(0), C.c_int(0)
+        _lib.check_plan(self.lib.mg_plan_copy_launches(self.handle, C.byref(a), C.byref(b)), self.handle)
+        return a.value, b.value
+
     def close(self):
         if self.handle:
             self.lib.mg_plan_destroy(self.handle)

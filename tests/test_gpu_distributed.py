@@ -212,6 +212,8 @@ def test_native_cycle_plan_equals_python_driver(px, py, NX, NY, agg, levels, cyc
         first = H.assemble(s, NX, NY, fdt)
         if native:
             assert s.native_cycles == 3 and s._plan is not None and s._plan.n > 10
+            copies, launches = s._plan.copy_launches()
+            assert 0 < launches < copies                     # runs of independent halo copies share a launch
         s.set_problem(lambda b: rhs2[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
         hist.append(s.residual_norm())
         for _ in range(2):

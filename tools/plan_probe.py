@@ -61,9 +61,9 @@ def main():
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
         u = [s.local_solution(r)[1] for r in s.ranks]
         out[native] = (hist, u)
-        nops = len(s._plan.keep) if s._plan else 0
+        copies = s._plan.copy_launches() if s._plan else (0, 0)
         print(f"native={native}: {px}x{py} virtual ranks, {n}^2 each, Ld={s.Ld}: {dt*1e3:.3f} ms/cycle -> {dt*1e3/(px*py):.3f} ms per rank-cycle"
-              f" (native cycles {s.native_cycles}, plan ops {s._plan.n if s._plan else 0})", flush=True)
+              f" (native cycles {s.native_cycles}, plan ops {s._plan.n if s._plan else 0}, {copies[0]} copies in {copies[1]} launches)", flush=True)
         s.close()
     same = out[False][0] == out[True][0] and all(np.array_equal(a, b) for a, b in zip(out[False][1], out[True][1]))
     print("bit-for-bit:", same)
