@@ -803,16 +803,23 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
   return sweeps;
 }
 
-// The same solve with as few instructions per time step as the arithmetic allows -- ONE wave issues an instruction every
-// ~5 cycles whatever it is, so lexgs_pipelined_5x5's ~270 instructions per sweep (per-lane time counters, ring / neighbour
-// selects, both division variants, a three-deep history shifted on every update) are what its ~1350 cycles per sweep are
-// made of.  Requirements: the ring of the iterate is zero (every coarsest problem below the top of a hierarchy is a
-// correction equation with homogeneous boundary values).  Then the nine unknowns sit in a 4-wide lane grid (lane = 4 ci +
-// cj, cj < 3) whose pad lanes hold 0.0, all four neighbours are plain DPP row shifts by 1 and 4 with bound_ctrl zeros
-// standing in for the ring, the anti-diagonal parity classes update under two constant lane masks on alternating time
-// steps (three masked start-up steps), and the snapshot the stop test needs is the current value, the previous one or the
-// one before, by a per-lane constant.  Same expressions in the same order as lexgs_pipelined_5x5 (sums with an exact zero
-// instead of a selected ring value), same sweep count; the nine squares of the stop test are added in another lane order.
+// The same solve with as few instructions per sweep as the arithmetic allows -- ONE wave issues an instruction every ~5-6
+// cycles whatever it is, so lexgs_pipelined_5x5's ~270 instructions per sweep (per-lane time counters, ring / neighbour
+// selects, both division variants, a three-deep history shifted on every update, a stop test per sweep) are what its ~1350
+// cycles per sweep are made of.  Requirement: the ring of the iterate is zero (every coarsest problem below the top of a
+// hierarchy is a correction equation with homogeneous boundary values).  Then
+//  * the nine unknowns sit in a 4-wide lane grid (lane = 4 ci + cj, cj < 3) whose pad lanes hold 0.0: all four neighbours
+//    are plain DPP row shifts by 1 and 4, bound_ctrl zeros standing in for the ring;
+//  * the anti-diagonal parity classes update under two constant lane masks on alternating time steps (three masked
+//    start-up steps);
+//  * the sweep-k snapshot the stop test needs is, by a per-lane constant, the current value or the value at the start of
+//    this / the previous sweep's pair of steps (two plain copies per sweep instead of a shifted history);
+//  * all four 16-lane rows of the wave run the SAME solve, so -- after the first four sweeps of a warm start, which are
+//    tested one by one -- row r evaluates the stop test of the r-th of four sweeps from its own copy of that snapshot: one residual / reduction
+//    / compare per four sweeps.  The first sweep that meets the tolerance (or maxit) is the result; up to three sweeps
+//    past it are speculative and dropped.
+// Same expressions in the same order as lexgs_pipelined_5x5 (sums with an exact zero instead of a selected ring value), same
+// sweep count; the nine squares of the stop test are added in another lane order.
 template <typename T, bool VAR, bool EXACT>
 __device__ int lexgs_5x5_zero_ring(T* __restrict__ su, const T* __restrict__ sf, T hx2, T hy2, T diag, T coeff, T omega, T one_m_omega,
                                    double hxhy, double tol_x, int maxit, int lane, const T* __restrict__ sa, T sigma) {
@@ -824,8 +831,9 @@ __device__ int lexgs_5x5_zero_ring(T* __restrict__ su, const T* __restrict__ sf,
     if (i == 0 || i == 4 || j == 0 || j == 4) ring = (double)sf[lane] * (double)sf[lane];
   }
   ring = wave_first(wave_reduce_sum(ring));
-  const int ci = lane >> 2, cj = lane & 3;
-  const bool mine = lane < 11 && cj < 3;
+  const int row = lane >> 4, cl = lane & 15;
+  const int ci = cl >> 2, cj = cl & 3;
+  const bool mine = cl < 11 && cj < 3;
   const int g = mine ? (ci + 1) * ny + cj + 1 : ny + 1, d = ci + cj + 2;
   const T fv = mine ? sf[g] : T(0);
   T uv = mine ? su[g] : T(0);
@@ -837,7 +845,6 @@ __device__ int lexgs_5x5_zero_ring(T* __restrict__ su, const T* __restrict__ sf,
   }
   const bool even = mine && !(d & 1), odd = mine && (d & 1);
   const bool lead1 = mine && (d == 3 || d == 4), lead2 = mine && d == 2;   // sweeps ahead of the sweep under test
-  T h1 = uv, h2 = uv;                                                      // the lane's previous two sweep values
   auto step = [&](bool upd) {
     const T up = dpp_row_move<0x114>(uv), dn = dpp_row_move<0x104>(uv);    // row_shr:4 / row_shl:4: lanes c -+ 4
     const T lf = dpp_row_move<0x111>(uv), rt = dpp_row_move<0x101>(uv);
@@ -846,34 +853,68 @@ __device__ int lexgs_5x5_zero_ring(T* __restrict__ su, const T* __restrict__ sf,
     const T num = fv + nb;
     const T un = VAR ? num / Dv : (EXACT ? num * rdiag : num / diag);
     const T nv = one_m_omega * uv + omega * un;
-    h2 = upd ? h1 : h2;
-    h1 = upd ? uv : h1;
     uv = upd ? nv : uv;
   };
   // cell on anti-diagonal d takes its sweep-k value at time 2k + d: t = 4, 5, 6 start the pipeline, from t = 7 on every
-  // odd (even) time step updates all odd (even) anti-diagonals
+  // odd (even) time step updates all odd (even) anti-diagonals.  p1 / p2: the values after time 2k + 4 / 2k + 2.
   step(mine && d == 2);
+  T p1 = uv, p2 = uv;
   step(mine && d == 3);
   step(mine && (d == 2 || d == 4));
   int sweeps = maxit;
   T result = uv;
-  for (int k = 1;; ++k) {
-    step(odd);
-    step(even);                                    // t = 2k + 6: the last cell has its sweep-k value
-    const T snap = lead2 ? h2 : (lead1 ? h1 : uv);
+  // the stop test of ONE snapshot (every row evaluates the same one) / of four (row r: the r-th)
+  auto sumsq = [&](T snap) {
     const T up = dpp_row_move<0x114>(snap), dn = dpp_row_move<0x104>(snap);
     const T lf = dpp_row_move<0x111>(snap), rt = dpp_row_move<0x101>(snap);
     const T sx = VAR ? aip * dn + aim * up : dn + up, sy = VAR ? ajp * rt + ajm * lf : rt + lf;
     const T rv = fv - coeff * ((EXACT ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2) - snap * (VAR ? Dv : diag));
-    double acc = mine ? (double)rv * (double)rv : 0.0;
-    acc = wave_first(row0_reduce_sum(acc));
+    const double acc = mine ? (double)rv * (double)rv : 0.0;
+    return row0_reduce_sum(acc);                   // per 16-lane row: the sum of its nine squares in the row's first lane
+  };
+  // A solve that starts from zero (the first visit of a coarsest problem) needs tens of sweeps: tested four at a time from
+  // the start.  One that starts from an iterate (the second visit inside a W / F cycle) stops after a few: its first
+  // kSingle sweeps are tested one by one, without speculative sweeps.
+  constexpr int kSingle = 4;
+  const int nsingle = (__ballot(uv != T(0)) == 0ull) ? 0 : kSingle;
+  bool done = false;
+  for (int k = 1; k <= nsingle; ++k) {
+    p2 = p1;
+    p1 = uv;
+    step(odd);
+    step(even);                                    // t = 2k + 6: the last cell has its sweep-k value
+    const T snap = lead2 ? p2 : (lead1 ? p1 : uv);
+    const double acc = wave_first(sumsq(snap));
     if (hxhy * (acc + ring) < tol_x || k >= maxit) {
       result = snap;
       sweeps = k;
+      done = true;
       break;
     }
   }
-  if (mine) su[g] = result;
+  if (!done) {
+    for (int k0 = nsingle + 1;; k0 += 4) {
+      T s[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        p2 = p1;
+        p1 = uv;
+        step(odd);
+        step(even);
+        s[j] = lead2 ? p2 : (lead1 ? p1 : uv);
+      }
+      const double acc = sumsq(row == 0 ? s[0] : (row == 1 ? s[1] : (row == 2 ? s[2] : s[3])));
+      const bool stop = cl == 0 && (hxhy * (acc + ring) < tol_x || k0 + row >= maxit);
+      const unsigned long long m = __ballot(stop);
+      if (m) {
+        const int r = (__ffsll((long long)m) - 1) >> 4;   // the first of the four sweeps that stops
+        result = r == 0 ? s[0] : (r == 1 ? s[1] : (r == 2 ? s[2] : s[3]));
+        sweeps = k0 + r;
+        break;
+      }
+    }
+  }
+  if (mine && row == 0) su[g] = result;
   wave_lds_fence<T>();
   return sweeps;
 }
