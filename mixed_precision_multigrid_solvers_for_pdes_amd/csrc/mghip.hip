@@ -1713,6 +1713,7 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
   const bool can_spec = h->cfg.speculate != 0 && h->fused() && h->L() > 1 && h->mbox_dev && h->cfg.pre <= 2 &&
                         h->cfg.post <= 2 && !h->cfg.profile && h->ring_sumsq[0] >= 0 && h->ring_sumsq[1] >= 0;
   bool spec = false;       // the front part of the coming cycle is already queued
+  double prev_rn = 0;      // the norm before `rn` (speculation heuristics)
   auto undo_front = [&]() {
     Level& v0 = h->lv[0];
     const int d0 = h->level_dtype(0);
@@ -1740,7 +1741,21 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
       spec = false;
       if ((rc = cycle_fused(h, 0, false, kPartBack)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
       const unsigned long long seq = reduce_post(h, h->norm_partials);
-      if (it < max_iter) {
+      // A queued front part is wasted work when the norm in flight switches the working precision (its level-0 leg runs
+      // in the old one): extrapolate the norm in flight from the last two of the fp32 phase and do not speculate across a
+      // switch the policy would take on it (threshold reached, or the stagnation window filling up with a flat history).
+      bool switch_likely = false;
+      if (h->cfg.precision == MG_PREC_ADAPTIVE && h->phase == MG_F32 && !h->promoted && !h->cfg.adaptive_reference_rule &&
+          h->adapt_hist.size() >= 2) {
+        const double prev = h->adapt_hist[h->adapt_hist.size() - 2];
+        const double rho = prev > 0 ? std::min(1.0, rn / prev) : 1.0;
+        std::vector<double> guess(h->adapt_hist);
+        guess.push_back(rn * rho);
+        switch_likely = rn * rho < h->cfg.switch_threshold * 10 || stagnating(guess);
+      }
+      // ... nor across the end of the solve: the norm in flight, extrapolated the same way, meets the tolerance
+      if (it >= 2 && prev_rn > 0 && rn * std::min(1.0, rn / prev_rn) < tol) switch_likely = true;
+      if (it < max_iter && !switch_likely) {
         if ((rc = cycle_fused(h, 0, false, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
         spec = true;
       }
@@ -1748,6 +1763,7 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
       double ss = 0;
       if ((rc = reduce_wait(h, seq, &ss)) != MG_OK) return rc;
       const int d0 = h->level_dtype(0);
+      prev_rn = rn;
       rn = std::sqrt(h->lv[0].hx * h->lv[0].hy * (ss + h->ring_sumsq[d0]));
       if (spec) h->norm_partials = 0;        // `partials` still describes cycle `it`, but lv[0].u is ahead of it
     } else {
