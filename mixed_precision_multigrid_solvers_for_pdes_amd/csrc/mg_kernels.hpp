@@ -622,6 +622,22 @@ __global__ __launch_bounds__(kBlock) void convert_kernel(const TIN* __restrict__
   }
 }
 
+// The boundary ring only (rows 0 and nx-1, columns 0 and ny-1): what the ping-pong partner of an iterate needs -- the
+// fused legs rewrite its interior and keep its ring.
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(kBlock) void convert_ring_kernel(const TIN* __restrict__ in, TOUT* __restrict__ out, int nx,
+                                                              int ny, int ldi, int ldo) {
+  const int total = 2 * ny + 2 * nx;
+  for (int v = blockIdx.x * kBlock + threadIdx.x; v < total; v += gridDim.x * kBlock) {
+    int i, j;
+    if (v < ny) { i = 0; j = v; }
+    else if (v < 2 * ny) { i = nx - 1; j = v - ny; }
+    else if (v < 2 * ny + nx) { i = v - 2 * ny; j = 0; }
+    else { i = v - 2 * ny - nx; j = ny - 1; }
+    out[(size_t)i * ldo + j] = (TOUT)in[(size_t)i * ldi + j];
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // Coarsest-grid solver: lexicographic Gauss-Seidel sweeps until sqrt(hx*hy*sum r^2) < tol or maxit.
 //   reference: solvers/smoothers.py:153-173 driven by IterativeSolver.solve solvers/base.py:255-290

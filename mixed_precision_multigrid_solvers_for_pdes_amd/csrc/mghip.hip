@@ -275,6 +275,18 @@ void d_convert(int di, int dout, const void* in, void* out, int nx, int ny, int 
   else if (di == MG_F64 && dout == MG_F32) launch_convert<double, float>(in, out, nx, ny, ldi, ldo, st);
   else launch_convert<float, double>(in, out, nx, ny, ldi, ldo, st);
 }
+template <typename TI, typename TO>
+void launch_convert_ring(const void* in, void* out, int nx, int ny, int ldi, int ldo, hipStream_t st) {
+  hipLaunchKernelGGL((mg::convert_ring_kernel<TI, TO>), dim3(grid_for(2LL * nx + 2LL * ny)), dim3(mg::kBlock), 0, st,
+                     (const TI*)in, (TO*)out, nx, ny, ldi, ldo);
+}
+// boundary ring of `in` -> boundary ring of `out` (the interior of `out` is left alone)
+void d_convert_ring(int di, int dout, const void* in, void* out, int nx, int ny, int ldi, int ldo, hipStream_t st) {
+  if (di == MG_F32 && dout == MG_F32) launch_convert_ring<float, float>(in, out, nx, ny, ldi, ldo, st);
+  else if (di == MG_F64 && dout == MG_F64) launch_convert_ring<double, double>(in, out, nx, ny, ldi, ldo, st);
+  else if (di == MG_F64 && dout == MG_F32) launch_convert_ring<double, float>(in, out, nx, ny, ldi, ldo, st);
+  else launch_convert_ring<float, double>(in, out, nx, ny, ldi, ldo, st);
+}
 void d_zero_interior(int dt, void* u, int nx, int ny, int ld, hipStream_t st) {
   if (nx < 3 || ny < 3) return;
   const long long vecs = (long long)(nx - 2) * ((ny + (int)(16 / esize(dt)) - 1) / (int)(16 / esize(dt)));
@@ -688,6 +700,8 @@ struct mg_handle {
   bool varcoef = false;          // A = coeff * div(a grad .) with the per-level fields lv[l].a
   double sigma = 0.0;            // Helmholtz shift: A = coeff * (Laplacian - sigma I) on every level (mg_set_shift)
   double ring_sumsq[2] = {0, 0};   // sum of f^2 over the boundary ring of the fine rhs, per dtype (r = f there)
+  unsigned rhs_gen = 1;            // bumped by every new right-hand side
+  unsigned rings_gen[2] = {0, 0};  // rhs_gen the coarse rhs rings of working precision p were injected for (adaptive policy)
   int norm_partials = 0;           // > 0: `partials` holds sum r^2 over interior cells of the CURRENT fine iterate
   int tail_start = -1;             // first level of the single-workgroup LDS tail (-1: none)
   int* d_tail_ops = nullptr;       // device copy of the tail schedule
@@ -1252,7 +1266,7 @@ int fine_norm(mg_handle* h, double* out) {
   return MG_OK;
 }
 
-void inject_rings(mg_handle* h, int ph);
+void inject_rings(mg_handle* h, int ph, bool only_shared = false);
 
 // in-device cast of the fine iterate when the adaptive policy changes the working precision
 int switch_phase(mg_handle* h, int to) {
@@ -1261,11 +1275,15 @@ int switch_phase(mg_handle* h, int to) {
   const int from = h->phase;
   if (h->L() > 1) {   // with a single level the only level is the coarsest and lives in the grid dtype
     d_convert(from, to, v.u[from], v.u[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
-    if (v.t[to]) d_convert(from, to, v.u[from], v.t[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
+    // the ping-pong partner only needs the boundary ring (the first leg rewrites its interior)
+    if (v.t[to]) d_convert_ring(from, to, v.u[from], v.t[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
   }
   h->phase = to;
   h->norm_partials = 0;
-  if (h->have_rhs) inject_rings(h, to);
+  if (h->have_rhs) {     // once per right-hand side and working precision, except the arrays the two precisions share
+    inject_rings(h, to, h->rings_gen[to] == h->rhs_gen);
+    h->rings_gen[to] = h->rhs_gen;
+  }
   return MG_OK;
 }
 
@@ -1317,11 +1335,14 @@ int adapt(mg_handle* h, double rn) {
 // The boundary ring of every coarse rhs is the injected fine ring (r = f on boundary cells, injection on the
 // coarse boundary: operators/laplacian.py:117-118, operators/transfer.py:109-113): constant over a solve, so it
 // is written here once per rhs (and per working precision) instead of in every cycle.
-void inject_rings(mg_handle* h, int ph) {
+// only_shared: just the coarse arrays that BOTH working precisions of the adaptive policy use (the fp64 coarsest level: its
+// ring is the injected ring of an fp32 rhs in one phase and of the fp64 rhs in the other); the rest is still valid.
+void inject_rings(mg_handle* h, int ph, bool only_shared) {
   for (int l = 0; l + 1 < h->L(); ++l) {
     Level& f = h->lv[l];
     Level& c = h->lv[l + 1];
     const int dt = h->level_dtype_in(l, ph), dc = h->level_dtype_in(l + 1, ph);
+    if (only_shared && h->level_dtype_in(l + 1, MG_F32) != h->level_dtype_in(l + 1, MG_F64)) continue;
     d_inject_ring(dt, dc, f.rhs[dt], c.rhs[dc], f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], h->stream);
   }
 }
@@ -1349,7 +1370,9 @@ int ring_sums(mg_handle* h) {
 int rhs_changed(mg_handle* h) {
   h->have_rhs = true;
   h->norm_partials = 0;
+  ++h->rhs_gen;
   inject_rings(h, h->phase);
+  h->rings_gen[h->phase & 1] = h->rhs_gen;
   return ring_sums(h);
 }
 
@@ -1365,14 +1388,22 @@ int set_rhs_impl(mg_handle* h, const void* rhs, int hdt) {
 
 int set_u_impl(mg_handle* h, const void* u0, int hdt) {
   Level& v = h->lv[0];
+  // Adaptive policy: every solve starts in double (PrecisionManager's default precision, core/precision.py:26-45), so a
+  // new initial guess goes straight into the fp64 iterate instead of being converted up when the solve begins
+  if (h->cfg.precision == MG_PREC_ADAPTIVE && h->phase != MG_F64 && h->L() > 1) {
+    h->phase = MG_F64;
+    if (h->have_rhs) {
+      inject_rings(h, MG_F64, h->rings_gen[MG_F64] == h->rhs_gen);
+      h->rings_gen[MG_F64] = h->rhs_gen;
+    }
+  }
   const int dt = h->iterate_dtype();
   h->norm_partials = 0;
   if (u0) {
     int rc = upload(&h->err, v.u[dt], dt, v.ld[dt], u0, hdt, v.nx, v.ny, h->staging, h->stream);
     if (rc != MG_OK) return rc;
-    if (v.t[dt]) {   // the ping-pong partner must carry the same boundary ring
-      HIPC(&h->err, hipMemcpyAsync(v.t[dt], v.u[dt], (size_t)v.nx * v.ld[dt] * esize(dt), hipMemcpyDeviceToDevice, h->stream));
-    }
+    if (v.t[dt])     // the ping-pong partner must carry the same boundary ring
+      d_convert_ring(dt, dt, v.u[dt], v.t[dt], v.nx, v.ny, v.ld[dt], v.ld[dt], h->stream);
   } else {
     HIPC(&h->err, hipMemsetAsync(v.u[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
     if (v.t[dt]) HIPC(&h->err, hipMemsetAsync(v.t[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
@@ -1530,7 +1561,9 @@ int mg_set_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype) {
     if (v.rhs[dt]) d_convert(dtype, dt, rhs_dev, v.rhs[dt], v.nx, v.ny, ld, v.ld[dt], h->stream);
   h->have_rhs = true;
   h->norm_partials = 0;
+  ++h->rhs_gen;
   inject_rings(h, h->phase);        // asynchronous; the ring sum (host round trip) is only needed by mg_residual_norm
+  h->rings_gen[h->phase & 1] = h->rhs_gen;
   h->ring_sumsq[0] = h->ring_sumsq[1] = -1.0;
   HIPC(&h->err, hipGetLastError());
   return MG_OK;
