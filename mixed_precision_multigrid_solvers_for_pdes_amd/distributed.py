@@ -884,7 +884,11 @@ class DistributedMultigrid:
             b = d.blk[0]
             d.u[0][:b.lnx, :b.lny].copy_(other.doms[r].u[0][:b.lnx, :b.lny])      # torch casts on the device; pitches differ
             if d.t[0] is not None:
-                d.t[0].copy_(d.u[0])
+                # the ping-pong partner only needs the outermost ring (Dirichlet values on physical edges; the legs rewrite
+                # everything inside it)
+                u, t = d.u[0], d.t[0]
+                t[0, :b.lny].copy_(u[0, :b.lny]); t[b.lnx - 1, :b.lny].copy_(u[b.lnx - 1, :b.lny])
+                t[:b.lnx, 0].copy_(u[:b.lnx, 0]); t[:b.lnx, b.lny - 1].copy_(u[:b.lnx, b.lny - 1])
         self._last_norm_parts = None
         self._norm_value = None
 
