@@ -702,6 +702,9 @@ struct mg_handle {
   double ring_sumsq[2] = {0, 0};   // sum of f^2 over the boundary ring of the fine rhs, per dtype (r = f there)
   unsigned rhs_gen = 1;            // bumped by every new right-hand side
   unsigned rings_gen[2] = {0, 0};  // rhs_gen the coarse rhs rings of working precision p were injected for (adaptive policy)
+  bool iterate_zero = false;       // the fine iterate is zero everywhere (mg_set_solution(NULL) / mg_zero_solution_device, no cycle since)
+  unsigned zero_norm_gen[2] = {0, 0};   // ||f - A 0|| = ||f|| as the norm kernel sums it, per dtype, for right-hand side rhs_gen
+  double zero_norm_val[2] = {0, 0};
   int norm_partials = 0;           // > 0: `partials` holds sum r^2 over interior cells of the CURRENT fine iterate
   int tail_start = -1;             // first level of the single-workgroup LDS tail (-1: none)
   int* d_tail_ops = nullptr;       // device copy of the tail schedule
@@ -1086,6 +1089,7 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
 // `ncyc` cycles of the sub-hierarchy that starts at level l.  The boundary ring of the fine iterate (Dirichlet data)
 // is kept; coarser rings are zero.
 int fmg_init(mg_handle* h, int ncyc) {
+  h->iterate_zero = false;
   const int L = h->L();
   if (L < 2) return MG_OK;
   h->norm_partials = 0;
@@ -1160,6 +1164,7 @@ int launch_defect(mg_handle* h, bool update) {
 // one fp32 cycle from the zero correction on the current defect (left in lv[0].u[fp32])
 int defect_cycle(mg_handle* h) {
   h->norm_partials = 0;
+  h->iterate_zero = false;
   if (h->L() == 1) {                     // a single level: the "cycle" is the coarsest solve, in the grid dtype (fp64)
     return MG_ERR_INVALID_VALUE;
   }
@@ -1171,6 +1176,7 @@ int defect_cycle(mg_handle* h) {
 
 int run_cycle(mg_handle* h) {
   h->norm_partials = 0;
+  h->iterate_zero = false;
   if (h->cfg.precision == MG_PREC_DEFECT) {            // one outer step: defect, fp32 cycle, update
     if (h->varcoef) return MG_ERR_INVALID_VALUE;
     (void)launch_defect(h, false);
@@ -1254,6 +1260,9 @@ int fine_norm(mg_handle* h, double* out) {
     *out = std::sqrt(v.hx * v.hy * (ss + h->ring_sumsq[dt]));
     return MG_OK;
   }
+  // the norm of the zero iterate is ||f||, whatever the operator: computed once per right-hand side (by the same kernel, so
+  // with the same bits) and remembered -- repeated solves of one right-hand side from the zero guess skip the pass
+  if (h->iterate_zero && h->zero_norm_gen[dt] == h->rhs_gen) { *out = h->zero_norm_val[dt]; return MG_OK; }
   const int n = h->varcoef
       ? d_var<mg::kVarResidualNorm>(dt, v.u[dt], v.a[dt], v.rhs[dt], nullptr, h->partials, v.nx, v.ny, v.ld[dt], v.hx, v.hy,
                                     1.0, h->cfg.coeff, 0, 0, h->stream, h->sigma)
@@ -1263,6 +1272,7 @@ int fine_norm(mg_handle* h, double* out) {
   const int rc = reduce_to_host(h, n, &ss);
   if (rc != MG_OK) return rc;
   *out = std::sqrt(v.hx * v.hy * ss);
+  if (h->iterate_zero) { h->zero_norm_gen[dt] = h->rhs_gen; h->zero_norm_val[dt] = *out; }
   return MG_OK;
 }
 
@@ -1399,6 +1409,7 @@ int set_u_impl(mg_handle* h, const void* u0, int hdt) {
   }
   const int dt = h->iterate_dtype();
   h->norm_partials = 0;
+  h->iterate_zero = (u0 == nullptr);
   if (u0) {
     int rc = upload(&h->err, v.u[dt], dt, v.ld[dt], u0, hdt, v.nx, v.ny, h->staging, h->stream);
     if (rc != MG_OK) return rc;
@@ -1573,6 +1584,7 @@ int mg_zero_solution_device(mg_handle* h) {
   if (!h) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL handle");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
   h->norm_partials = 0;
+  h->iterate_zero = true;
   Level& v = h->lv[0];
   const int dt = h->iterate_dtype();
   HIPC(&h->err, hipMemsetAsync(v.u[dt], 0, (size_t)v.nx * v.ld[dt] * esize(dt), h->stream));
@@ -1712,6 +1724,7 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
   double rn = 0;
   int rc = fine_norm(h, &rn);
   if (rc != MG_OK) return rc;
+  h->iterate_zero = false;                    // cycles follow
   st->initial_residual = rn;
   int it = 0, conv = 0, switches = 0;
   if (h->cfg.precision == MG_PREC_DEFECT) {

@@ -245,6 +245,48 @@ def test_speculative_launching_changes_nothing(prec, thr):
     np.testing.assert_array_equal(ra2["residual_history"], rb2["residual_history"])
 
 
+@pytest.mark.parametrize("prec", ["double", "adaptive", "single"])
+def test_repeated_solves_and_adaptive_switches_leave_no_trace(prec):
+    """What the adaptive path keeps between solves -- the norm of the zero iterate per right-hand side, the injected coarse
+    rhs rings per working precision, the ring-only ping-pong partner after a precision switch, a new guess stored straight
+    into the fp64 iterate -- must not be visible: a second solve of the same right-hand side, a solve after another
+    right-hand side, and a solve from a non-zero guess all equal a fresh engine's, bit for bit."""
+    from mixed_precision_multigrid_solvers_for_pdes_amd import _lib
+    code = {"double": _lib.MG_PREC_DOUBLE, "single": _lib.MG_PREC_SINGLE_MANAGED, "adaptive": _lib.MG_PREC_ADAPTIVE}[prec]
+    n = 513
+    rng = np.random.default_rng(3)
+    rhs_a, rhs_b = O.sine_rhs(n, n), rng.standard_normal((n, n))
+    u0 = rng.standard_normal((n, n))
+    kw = dict(max_levels=8, smoother=_lib.MG_JACOBI, omega=0.8, precision=code, switch_threshold=1e-4)
+
+    def fresh(rhs, guess, iters):
+        eng = mg.MultigridEngine(n, n, **kw)
+        eng.set_rhs(rhs); eng.set_solution(guess)
+        r = eng.iterate(0.0, iters)
+        u = eng.get_solution()
+        eng.close()
+        return u, r
+
+    eng = mg.MultigridEngine(n, n, **kw)
+    eng.set_rhs(rhs_a)
+    runs, resident = [], rhs_a
+    for rhs, guess, iters in ((rhs_a, None, 3), (rhs_a, None, 9), (rhs_b, None, 4), (rhs_a, u0, 9), (rhs_a, None, 2)):
+        if rhs is not resident:
+            eng.set_rhs(rhs)
+            resident = rhs
+        eng.set_solution(guess)
+        r = eng.iterate(0.0, iters)
+        runs.append((rhs, guess, iters, eng.get_solution(), r))
+    eng.close()
+    for rhs, guess, iters, u, r in runs:
+        u_ref, r_ref = fresh(rhs, guess, iters)
+        np.testing.assert_array_equal(u, u_ref)
+        assert r["residual_history"] == r_ref["residual_history"] and r["initial_residual"] == r_ref["initial_residual"]
+        assert r["precision_codes"] == r_ref["precision_codes"]
+    if prec == "adaptive":
+        assert 0 in runs[1][4]["precision_codes"] and 1 in runs[1][4]["precision_codes"]      # the 9-cycle solve did switch
+
+
 def test_bench_size_4097_two_cycles_equal_oracle():
     """At the bench size itself: two V(2,2) Jacobi cycles of the fused fp64 engine at 4097^2 against the NumPy oracle
     (about 1 s per oracle cycle) -- bit-identical iterate, norms to reduction round-off."""
