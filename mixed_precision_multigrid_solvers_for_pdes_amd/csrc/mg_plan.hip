@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -426,7 +428,22 @@ int mg_plan_run(mg_plan* p, void* compute_stream, void* comm_stream, double* res
   PLAN_HIP(p, hipGetLastError());
   if (result_dev) {
     PLAN_HIP(p, hipMemcpyAsync(p->result_host, result_dev, sizeof(double), hipMemcpyDeviceToHost, result_stream));
-    PLAN_HIP(p, hipStreamSynchronize(result_stream));
+    if (p->comm) {
+      // a plan that talks to other ranks waits with a deadline: a peer that never posts its half of an exchange must end in
+      // an error here, not in a process that hangs until somebody kills it (MG_PLAN_TIMEOUT_S, default 120 s)
+      static const double limit = [] { const char* e = std::getenv("MG_PLAN_TIMEOUT_S"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 120.0; }();
+      const auto t0 = std::chrono::steady_clock::now();
+      for (long spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(result_stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return plan_fail(&p->err, MG_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        if ((spins & 1023) == 1023 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+          return plan_fail(&p->err, MG_ERR_HIP, "cycle plan: no result after MG_PLAN_TIMEOUT_S seconds (a peer rank is not taking part in an exchange?)");
+      }
+    } else {
+      PLAN_HIP(p, hipStreamSynchronize(result_stream));
+    }
     if (result) *result = *p->result_host;
   }
   return MG_OK;
