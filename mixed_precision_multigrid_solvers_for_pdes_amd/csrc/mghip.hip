@@ -1279,12 +1279,15 @@ int fine_norm(mg_handle* h, double* out) {
 void inject_rings(mg_handle* h, int ph, bool only_shared = false);
 
 // in-device cast of the fine iterate when the adaptive policy changes the working precision
-int switch_phase(mg_handle* h, int to) {
+// iterate_is_zero: the iterate is zero everywhere and the caller starts the coming cycle from the zero iterate without
+// reading it (cycle_fused(..., zero_u = true)): only the (zero) boundary rings of the two buffers are written.
+int switch_phase(mg_handle* h, int to, bool iterate_is_zero = false) {
   if (h->cfg.precision != MG_PREC_ADAPTIVE || to == h->phase) return MG_OK;
   Level& v = h->lv[0];
   const int from = h->phase;
   if (h->L() > 1) {   // with a single level the only level is the coarsest and lives in the grid dtype
-    d_convert(from, to, v.u[from], v.u[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
+    if (iterate_is_zero) d_convert_ring(from, to, v.u[from], v.u[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
+    else d_convert(from, to, v.u[from], v.u[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
     // the ping-pong partner only needs the boundary ring (the first leg rewrites its interior)
     if (v.t[to]) d_convert_ring(from, to, v.u[from], v.t[to], v.nx, v.ny, v.ld[from], v.ld[to], h->stream);
   }
@@ -1335,11 +1338,11 @@ int adapt_target(const mg_handle* h, double rn, bool* promote) {
   return to;
 }
 
-int adapt(mg_handle* h, double rn) {
+int adapt(mg_handle* h, double rn, bool iterate_is_zero = false) {
   bool promote = false;
   const int to = adapt_target(h, rn, &promote);
   if (promote) h->promoted = true;
-  return switch_phase(h, to);
+  return switch_phase(h, to, iterate_is_zero);
 }
 
 // The boundary ring of every coarse rhs is the injected fine ring (r = f on boundary cells, injection on the
@@ -1724,6 +1727,7 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
   double rn = 0;
   int rc = fine_norm(h, &rn);
   if (rc != MG_OK) return rc;
+  const bool zero_start = h->iterate_zero;    // the first cycle may start from the zero iterate without reading it
   h->iterate_zero = false;                    // cycles follow
   st->initial_residual = rn;
   int it = 0, conv = 0, switches = 0;
@@ -1760,6 +1764,7 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
                         h->cfg.post <= 2 && !h->cfg.profile && h->ring_sumsq[0] >= 0 && h->ring_sumsq[1] >= 0;
   bool spec = false;       // the front part of the coming cycle is already queued
   double prev_rn = 0;      // the norm before `rn` (speculation heuristics)
+  const bool zero_first = zero_start && can_spec && h->cfg.pre >= 1;
   auto undo_front = [&]() {
     Level& v0 = h->lv[0];
     const int d0 = h->level_dtype(0);
@@ -1775,7 +1780,9 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
       if (adapt_target(h, rn, &promote) != h->phase) undo_front();
       if ((rc = adapt(h, rn)) != MG_OK) return rc;
     } else {
-      if ((rc = adapt(h, rn)) != MG_OK) return rc;               // solvers/multigrid.py:224-227
+      // a solve from the zero guess: the first cycle's level-0 down leg runs from the zero iterate without reading it
+      // (the kernels' ZERO_INIT form, as on every coarse level), so a precision switch before it has nothing to convert
+      if ((rc = adapt(h, rn, zero_first && it == 1)) != MG_OK) return rc;               // solvers/multigrid.py:224-227
     }
     if (h->phase != before) {
       ++switches;
@@ -1783,7 +1790,7 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
     }
     if (can_spec) {
       h->norm_partials = 0;
-      if (!spec && (rc = cycle_fused(h, 0, false, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+      if (!spec && (rc = cycle_fused(h, 0, zero_first && it == 1, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
       spec = false;
       if ((rc = cycle_fused(h, 0, false, kPartBack)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
       const unsigned long long seq = reduce_post(h, h->norm_partials);
