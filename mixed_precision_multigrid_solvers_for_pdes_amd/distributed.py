@@ -469,58 +469,70 @@ class DistributedMultigrid:
             req.wait()
 
     def exchange(self, name, l, corners=False):
-        """Fill the ghost zone (G cells wide) of field `name` on level l from the neighbours' owned cells next to the
-        cut.  Rows first (whole rows: contiguous memory, no packing), then columns over the full local height, so the
-        corners arrive too."""
-        torch = self.torch
+        """Fill the ghost zone (G cells wide) of field `name` on level l from the neighbours' owned cells next to the cut,
+        in ONE communication step: whole rows to the row neighbours (contiguous memory, no packing), packed columns over
+        the full local height to the column neighbours, packed G x G corners to the diagonal neighbours.  Rows and columns
+        carry stale data where they cross the receiver's corner regions; the corner blocks are unpacked last."""
         G = self.G
         self.exchanges += 1
         fields = {r: (getattr(d, name)[l] if isinstance(getattr(d, name), list) else getattr(d, name)) for r, d in self.doms.items()}
-        # phase 1: rows
-        sends, recvs, local = [], [], []
+
+        def rows_of(b, dx, ghost):       # the G rows next to the cut towards dx: the ghost rows, or the owned rows beside them
+            if ghost:
+                return slice(b.oi_lo - G, b.oi_lo) if dx < 0 else slice(b.oi_hi + 1, b.oi_hi + 1 + G)
+            return slice(b.oi_lo, b.oi_lo + G) if dx < 0 else slice(b.oi_hi - G + 1, b.oi_hi + 1)
+
+        def cols_of(b, dy, ghost):
+            if ghost:
+                return slice(b.oj_lo - G, b.oj_lo) if dy < 0 else slice(b.oj_hi + 1, b.oj_hi + 1 + G)
+            return slice(b.oj_lo, b.oj_lo + G) if dy < 0 else slice(b.oj_hi - G + 1, b.oj_hi + 1)
+
+        sends, recvs = [], []
+        # in-process neighbours: copies, grouped so that runs of them do not touch each other (the plan executor launches such
+        # a run as one kernel): all rows, all columns, then the corners (they overwrite what rows and columns left there)
+        local = {"row": [], "col": [], "corner": []}
+        unpack = {"col": [], "corner": []}
         for r, d in self.doms.items():
             b, t = d.blk[l], fields[r]
-            for dx in (-1, +1):
-                p = self._nbr(d, dx, 0)
-                if p is None:
-                    continue
-                src = slice(b.oi_lo, b.oi_lo + G) if dx < 0 else slice(b.oi_hi - G + 1, b.oi_hi + 1)
-                dst = slice(b.oi_lo - G, b.oi_lo) if dx < 0 else slice(b.oi_hi + 1, b.oi_hi + 1 + G)
-                if p in self.doms:       # neighbour lives in this process: read its owned rows directly
-                    pb = self.doms[p].blk[l]
-                    psrc = slice(pb.oi_hi - G + 1, pb.oi_hi + 1) if dx < 0 else slice(pb.oi_lo, pb.oi_lo + G)
-                    local.append((t[dst, :b.lny], fields[p][psrc, :pb.lny]))
-                else:
-                    sends.append((p, t[src]))          # whole padded rows: one contiguous chunk
-                    recvs.append((p, t[dst]))
-        for dst, src in local:
+            for dx in (-1, 0, +1):
+                for dy in (-1, 0, +1):
+                    if dx == 0 and dy == 0:
+                        continue
+                    p = self._nbr(d, dx, dy)
+                    if p is None:
+                        continue
+                    pb = self.doms[p].blk[l] if p in self.doms else None
+                    if dy == 0:                                   # row neighbour
+                        if pb is not None:
+                            local["row"].append((t[rows_of(b, dx, True), :b.lny], fields[p][rows_of(pb, -dx, False), :pb.lny]))
+                        else:
+                            sends.append((p, t[rows_of(b, dx, False)]))      # whole padded rows: one contiguous chunk
+                            recvs.append((p, t[rows_of(b, dx, True)]))
+                    elif dx == 0:                                 # column neighbour
+                        if pb is not None:
+                            local["col"].append((t[:b.lnx, cols_of(b, dy, True)], fields[p][:pb.lnx, cols_of(pb, -dy, False)]))
+                        else:
+                            sbuf = self._buf(("pack", name, l, r, dy), (b.lnx, G), t.dtype, t.device)
+                            rbuf = self._buf(("unpack", name, l, r, dy), (b.lnx, G), t.dtype, t.device)
+                            self._copy(sbuf, t[:b.lnx, cols_of(b, dy, False)])
+                            sends.append((p, sbuf))
+                            recvs.append((p, rbuf))
+                            unpack["col"].append((t[:b.lnx, cols_of(b, dy, True)], rbuf))
+                    else:                                         # diagonal neighbour: the G x G corner
+                        dst = t[rows_of(b, dx, True), cols_of(b, dy, True)]
+                        if pb is not None:
+                            local["corner"].append((dst, fields[p][rows_of(pb, -dx, False), cols_of(pb, -dy, False)]))
+                        else:
+                            sbuf = self._buf(("cpack", name, l, r, dx, dy), (G, G), t.dtype, t.device)
+                            rbuf = self._buf(("cunpack", name, l, r, dx, dy), (G, G), t.dtype, t.device)
+                            self._copy(sbuf, t[rows_of(b, dx, False), cols_of(b, dy, False)])
+                            sends.append((p, sbuf))
+                            recvs.append((p, rbuf))
+                            unpack["corner"].append((dst, rbuf))
+        for dst, src in local["row"] + local["col"]:
             self._copy(dst, src)
         self._p2p(sends, recvs)
-        # phase 2: columns (strided: packed into contiguous buffers)
-        sends, recvs, local, unpack = [], [], [], []
-        for r, d in self.doms.items():
-            b, t = d.blk[l], fields[r]
-            for dy in (-1, +1):
-                p = self._nbr(d, 0, dy)
-                if p is None:
-                    continue
-                src = slice(b.oj_lo, b.oj_lo + G) if dy < 0 else slice(b.oj_hi - G + 1, b.oj_hi + 1)
-                dst = slice(b.oj_lo - G, b.oj_lo) if dy < 0 else slice(b.oj_hi + 1, b.oj_hi + 1 + G)
-                if p in self.doms:
-                    pb = self.doms[p].blk[l]
-                    psrc = slice(pb.oj_hi - G + 1, pb.oj_hi + 1) if dy < 0 else slice(pb.oj_lo, pb.oj_lo + G)
-                    local.append((t[:b.lnx, dst], fields[p][:pb.lnx, psrc]))
-                else:
-                    sbuf = self._buf(("pack", name, l, r, dy), (b.lnx, G), t.dtype, t.device)
-                    rbuf = self._buf(("unpack", name, l, r, dy), (b.lnx, G), t.dtype, t.device)
-                    self._copy(sbuf, t[:b.lnx, src])
-                    sends.append((p, sbuf))
-                    recvs.append((p, rbuf))
-                    unpack.append((t[:b.lnx, dst], rbuf))
-        for dst, src in local:
-            self._copy(dst, src)
-        self._p2p(sends, recvs)
-        for dst, src in unpack:
+        for dst, src in unpack["col"] + local["corner"] + unpack["corner"]:
             self._copy(dst, src)
 
     def allreduce_sum(self, parts):
