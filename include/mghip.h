@@ -319,6 +319,10 @@ typedef struct mg_plan mg_plan;
 int mg_plan_create(const mg_plan_op* ops, int n_ops, void* comm, int device, mg_plan** out);
 /* enqueue every operation; when the plan has a RESULT, wait for it and store it in *result */
 int mg_plan_run(mg_plan* plan, void* compute_stream, void* comm_stream, double* result);
+/* the two halves of mg_plan_run: enqueue (the RESULT travels to the host behind an event) / collect the RESULT.  Between them
+ * the caller may enqueue more work -- the front part of the next cycle -- so that the device does not wait for the host. */
+int mg_plan_run_async(mg_plan* plan, void* compute_stream, void* comm_stream);
+int mg_plan_wait(mg_plan* plan, double* result);
 int mg_plan_num_ops(const mg_plan* plan, int* n);
 /* COPY2D operations of the plan and the launches they run as (runs of independent copies share one launch) */
 int mg_plan_copy_launches(const mg_plan* plan, int* n_copies, int* n_launches);

@@ -113,6 +113,8 @@ SIGNATURES = {
     "mg_pitch_elems": (_i, [_i, _i, _pi]),
     "mg_plan_create": (_i, [C.POINTER(MgPlanOp), _i, _vp, _i, C.POINTER(_vp)]),
     "mg_plan_run": (_i, [_vp, _vp, _vp, _pd]),
+    "mg_plan_run_async": (_i, [_vp, _vp, _vp]),
+    "mg_plan_wait": (_i, [_vp, _pd]),
     "mg_plan_num_ops": (_i, [_vp, _pi]),
     "mg_plan_copy_launches": (_i, [_vp, _pi, _pi]),
     "mg_plan_error": (C.c_char_p, [_vp]),

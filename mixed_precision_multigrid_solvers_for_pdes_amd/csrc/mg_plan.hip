@@ -107,6 +107,8 @@ struct mg_plan {
   hipEvent_t ev[8] = {};
   double* result_dev = nullptr;
   double* result_host = nullptr;       // pinned
+  hipEvent_t done = nullptr;           // recorded behind the copy of the RESULT
+  bool pending = false;                // a RESULT is in flight (mg_plan_run_async) and not collected yet (mg_plan_wait)
   std::string err;
 };
 
@@ -297,6 +299,8 @@ int mg_plan_create(const mg_plan_op* ops, int n_ops, void* comm, int device, mg_
     e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
   }
+  e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+  if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
   e = hipHostMalloc(reinterpret_cast<void**>(&p->result_host), sizeof(double), hipHostMallocDefault);
   if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_ALLOC, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
   *out = p;
@@ -323,14 +327,16 @@ int mg_plan_destroy(mg_plan* p) {
   if (!p) return MG_OK;
   for (auto& ev : p->ev)
     if (ev) (void)hipEventDestroy(ev);
+  if (p->done) (void)hipEventDestroy(p->done);
   if (p->result_host) (void)hipHostFree(p->result_host);
   delete p;
   return MG_OK;
 }
 
-int mg_plan_run(mg_plan* p, void* compute_stream, void* comm_stream, double* result) {
-  if (!p) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_run: NULL plan");
+int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
+  if (!p) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_run_async: NULL plan");
   PLAN_HIP(p, hipSetDevice(p->device));
+  p->pending = false;
   hipStream_t st[2] = {static_cast<hipStream_t>(compute_stream), static_cast<hipStream_t>(comm_stream)};
   const double* result_dev = nullptr;
   hipStream_t result_stream = st[0];
@@ -428,25 +434,40 @@ int mg_plan_run(mg_plan* p, void* compute_stream, void* comm_stream, double* res
   PLAN_HIP(p, hipGetLastError());
   if (result_dev) {
     PLAN_HIP(p, hipMemcpyAsync(p->result_host, result_dev, sizeof(double), hipMemcpyDeviceToHost, result_stream));
-    if (p->comm) {
-      // a plan that talks to other ranks waits with a deadline: a peer that never posts its half of an exchange must end in
-      // an error here, not in a process that hangs until somebody kills it (MG_PLAN_TIMEOUT_S, default 120 s)
-      static const double limit = [] { const char* e = std::getenv("MG_PLAN_TIMEOUT_S"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 120.0; }();
-      const auto t0 = std::chrono::steady_clock::now();
-      for (long spins = 0;; ++spins) {
-        const hipError_t q = hipStreamQuery(result_stream);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) return plan_fail(&p->err, MG_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
-        if ((spins & 1023) == 1023 &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
-          return plan_fail(&p->err, MG_ERR_HIP, "cycle plan: no result after MG_PLAN_TIMEOUT_S seconds (a peer rank is not taking part in an exchange?)");
-      }
-    } else {
-      PLAN_HIP(p, hipStreamSynchronize(result_stream));
-    }
-    if (result) *result = *p->result_host;
+    PLAN_HIP(p, hipEventRecord(p->done, result_stream));
+    p->pending = true;
   }
   return MG_OK;
+}
+
+int mg_plan_wait(mg_plan* p, double* result) {
+  if (!p) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_wait: NULL plan");
+  if (!p->pending) return plan_fail(&p->err, MG_ERR_STATE, "mg_plan_wait: no result in flight (the plan has no RESULT, or it was already collected)");
+  if (p->comm) {
+    // a plan that talks to other ranks waits with a deadline: a peer that never posts its half of an exchange must end in
+    // an error here, not in a process that hangs until somebody kills it (MG_PLAN_TIMEOUT_S, default 120 s)
+    static const double limit = [] { const char* e = std::getenv("MG_PLAN_TIMEOUT_S"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 120.0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+      const hipError_t q = hipEventQuery(p->done);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) return plan_fail(&p->err, MG_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+      if ((spins & 1023) == 1023 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+        return plan_fail(&p->err, MG_ERR_HIP, "cycle plan: no result after MG_PLAN_TIMEOUT_S seconds (a peer rank is not taking part in an exchange?)");
+    }
+  } else {
+    PLAN_HIP(p, hipEventSynchronize(p->done));
+  }
+  p->pending = false;
+  if (result) *result = *p->result_host;
+  return MG_OK;
+}
+
+int mg_plan_run(mg_plan* p, void* compute_stream, void* comm_stream, double* result) {
+  const int rc = mg_plan_run_async(p, compute_stream, comm_stream);
+  if (rc != MG_OK || !p->pending) return rc;
+  return mg_plan_wait(p, result);
 }
 
 }  // extern "C"

@@ -22,6 +22,14 @@ class PlanRecorder:
         self.keep = []
         self.stream = 0
         self.n_comm = 0
+        self.split = None        # index of the first operation of the BACK part of the cycle (mark_split)
+
+    def mark_split(self):
+        """Everything recorded from here on is the back part of the cycle: the level-0 up legs and the norm.  The front part
+        (the level-0 down legs and everything below them) never writes the buffers that hold the iterate, so it can be queued
+        for the NEXT cycle before this cycle's norm has reached the host and simply be left unused if the solve ends there."""
+        if self.split is None:
+            self.split = len(self.ops)
 
     def emit(self, op, i=(), d=(), p=(), keep=()):
         o = _lib.MgPlanOp()
@@ -170,13 +178,15 @@ def shutdown():
 class CyclePlan:
     """mg_plan built from a recorder; `run` enqueues it and returns the RESULT (None without one)."""
 
-    def __init__(self, recorder, comm, device_index):
+    def __init__(self, recorder, comm, device_index, lo=0, hi=None):
+        """operations [lo, hi) of the recorder"""
         self.lib = _lib.load()
         self.keep = list(recorder.keep)
-        self.n = len(recorder.ops)
-        arr = (_lib.MgPlanOp * self.n)(*recorder.ops)
+        ops = recorder.ops[lo:hi]
+        self.n = len(ops)
+        arr = (_lib.MgPlanOp * self.n)(*ops)
         self.handle = C.c_void_p()
-        self.has_result = any(o.op == _lib.MG_PLAN_RESULT for o in recorder.ops)
+        self.has_result = any(o.op == _lib.MG_PLAN_RESULT for o in ops)
         _lib.check_plan(self.lib.mg_plan_create(arr, self.n, comm.handle if comm is not None else None, int(device_index),
                                                 C.byref(self.handle)))
 
@@ -186,6 +196,19 @@ class CyclePlan:
         if rc != _lib.MG_OK:
             _lib.check_plan(rc, self.handle)
         return out.value if self.has_result else None
+
+    def run_async(self, compute_stream, comm_stream):
+        """enqueue only; a RESULT is collected with wait()"""
+        rc = self.lib.mg_plan_run_async(self.handle, C.c_void_p(compute_stream), C.c_void_p(comm_stream))
+        if rc != _lib.MG_OK:
+            _lib.check_plan(rc, self.handle)
+
+    def wait(self):
+        out = C.c_double(0.0)
+        rc = self.lib.mg_plan_wait(self.handle, C.byref(out))
+        if rc != _lib.MG_OK:
+            _lib.check_plan(rc, self.handle)
+        return out.value
 
     def copy_launches(self):
         """(COPY2D operations, launches they run as)"""

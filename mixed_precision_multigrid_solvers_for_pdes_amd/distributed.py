@@ -412,6 +412,10 @@ class DistributedMultigrid:
         self._comm = None
         self._bufs = {}                          # persistent staging buffers (pack / unpack / gather)
         self._norm_value = None                  # sum of r^2 the last native cycle returned
+        self._plan_back = None                   # the plan is kept as two: front (level-0 down legs and below) / back (up legs, norm)
+        self._front_queued = False               # the front part of the COMING cycle is already on the streams
+        self._norm_pending = False               # the back part's sum of r^2 is still on its way to the host
+        self.speculate = True                    # queue the next cycle's front part before waiting for the norm
         self.native_cycles = 0
 
     # ---- primitives the plan recorder sees ------------------------------------------------------
@@ -631,8 +635,19 @@ class DistributedMultigrid:
         if self._plan is not None:
             self.torch.cuda.synchronize()
             self._plan.close()
-        self._plan = None
+            if self._plan_back is not None:
+                self._plan_back.close()
+        self._plan = self._plan_back = None
         self._plan_state = None
+        self._front_queued = self._norm_pending = False
+
+    def _settle(self):
+        """Before the iterate is replaced (new problem / coefficient / iterate): collect a norm still in flight and forget a
+        front part queued for a cycle that will not come."""
+        if self._norm_pending:
+            self._norm_value = self._plan_back.wait()
+            self._norm_pending = False
+        self._front_queued = False
 
     def _cycle_native(self):
         """The first cycle (and the first after anything moved a field to another buffer) runs through the Python driver
@@ -642,6 +657,7 @@ class DistributedMultigrid:
         torch = self.torch
         state = self._pointer_state()
         if self._plan is not None and self._plan_state != state:
+            self._settle()
             self._drop_plan()
         if self._plan is None:
             device = next(iter(self.doms.values())).u[0].device
@@ -663,7 +679,9 @@ class DistributedMultigrid:
             try:
                 if self.dist is not None and self._comm is None:
                     self._comm = dist_plan.shared_comm(self.dist, device.index or 0)
-                self._plan = dist_plan.CyclePlan(rec, self._comm, device.index or 0)
+                split = rec.split if rec.split is not None else len(rec.ops)
+                self._plan = dist_plan.CyclePlan(rec, self._comm, device.index or 0, 0, split)          # front part
+                self._plan_back = dist_plan.CyclePlan(rec, self._comm, device.index or 0, split, None)
                 self._plan_state = state
             except Exception as exc:
                 failure = exc
@@ -680,7 +698,19 @@ class DistributedMultigrid:
                 self.native_failure = repr(failure)
             return
         comm = self._comm_stream.cuda_stream if self.overlap else torch.cuda.current_stream().cuda_stream
-        self._norm_value = self._plan.run(torch.cuda.current_stream().cuda_stream, comm)
+        compute = torch.cuda.current_stream().cuda_stream
+        if self._norm_pending:                   # nobody asked for the previous cycle's norm
+            self._plan_back.wait()
+            self._norm_pending = False
+        if not self._front_queued:
+            self._plan.run_async(compute, comm)
+        self._plan_back.run_async(compute, comm)
+        self._norm_pending = True
+        # the front part of the NEXT cycle goes onto the streams before anybody waits for this cycle's norm: it reads the
+        # iterate this cycle leaves and writes only the other buffers, so a solve that ends here just leaves it unused
+        self._front_queued = bool(self.speculate)
+        if self._front_queued:
+            self._plan.run_async(compute, comm)
         self.native_cycles += 1
         self.exchanges += self._plan_exchanges
 
@@ -750,6 +780,8 @@ class DistributedMultigrid:
             for k in range(self._reps(l)):
                 self._cycle_fused(l + 1, k == 0, k == 0)
         want_norm = (l == 0)
+        if l == 0 and self._rec is not None:
+            self._rec.mark_split()               # what follows -- the level-0 up legs and the norm -- is the back part
         parts = {}
         for r, d in self.doms.items():
             b, bc = d.blk[l], d.blk[l + 1]
@@ -803,6 +835,7 @@ class DistributedMultigrid:
         Level l takes every 2^l-th fine vertex (injection, the single-GPU engine's rule), so every rank fills its blocks
         of every level -- ghost zones included -- from the function alone: no exchange.  None: constant coefficients."""
         torch = self.torch
+        self._settle()
         if a_at is None:
             self.var = False
             self.ops.coarse_coefficient(None)
@@ -825,6 +858,7 @@ class DistributedMultigrid:
     def set_problem(self, rhs_of_block, u0_of_block=None):
         """rhs_of_block(block) -> (lnx, lny) array of f on that block (ghost zone and boundary included)."""
         torch = self.torch
+        self._settle()
         for d in self.doms.values():
             b = d.blk[0]
             d.rhs[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(rhs_of_block(b), dtype=self.ldt[0])).to(d.rhs[0].device)
@@ -859,6 +893,9 @@ class DistributedMultigrid:
 
     def residual_norm(self):
         hx, hy = self.h[0]
+        if self._norm_pending:
+            self._norm_value = self._plan_back.wait()
+            self._norm_pending = False
         if self._norm_value is not None:            # a native cycle brought the sum back with it
             return math.sqrt(hx * hy * self._norm_value)
         if self._last_norm_parts is not None:       # the up leg of the last cycle already summed r^2 over the owned cells
@@ -892,6 +929,7 @@ class DistributedMultigrid:
     def take_iterate_from(self, other):
         """The fine iterate of `other` (same decomposition, another working precision) becomes this solver's iterate:
         the on-device cast of PrecisionManager.convert_array (core/precision.py:106-134), ghost zone included."""
+        self._settle()
         for r, d in self.doms.items():
             b = d.blk[0]
             d.u[0][:b.lnx, :b.lny].copy_(other.doms[r].u[0][:b.lnx, :b.lny])      # torch casts on the device; pitches differ
@@ -966,6 +1004,15 @@ class AdaptivePolicy:
     def after_cycle(self, rn):
         self.hist.append(rn)
 
+    def switch_likely(self):
+        """Will the norm of the cycle about to run change the precision?  Extrapolated from the last two norms of this
+        phase, as the engine does before it queues a speculative front part (csrc/mghip.hip, iterate_impl)."""
+        if self.promoted or self.phase != "f32" or len(self.hist) < 2:
+            return False
+        prev, last = self.hist[-2], self.hist[-1]
+        guess = last * (min(1.0, last / prev) if prev > 0 else 1.0)
+        return guess < 10.0 * self.thr or stagnating(self.hist + [guess])
+
 
 def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1): BASELINE config 3's workload per GPU (4097^2, adaptive fp32 -> fp64, V(2,2) weighted
@@ -1026,6 +1073,8 @@ def bench_main(args, rank, local_rank, world):
         now = policy.before_cycle(rn)
         if now != had:
             solvers[now].take_iterate_from(solvers[had])
+        # no speculative front part across a precision switch the policy can see coming (it would run and be dropped)
+        solvers[now].speculate = not policy.switch_likely()
         solvers[now].cycle(0)
         rn = solvers[now].residual_norm()
         policy.after_cycle(rn)

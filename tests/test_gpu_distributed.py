@@ -211,7 +211,7 @@ def test_native_cycle_plan_equals_python_driver(px, py, NX, NY, agg, levels, cyc
             s.cycle(0); hist.append(s.residual_norm())
         first = H.assemble(s, NX, NY, fdt)
         if native:
-            assert s.native_cycles == 3 and s._plan is not None and s._plan.n > 10
+            assert s.native_cycles == 3 and s._plan is not None and s._plan.n > 10 and s._plan_back.n >= 2
             copies, launches = s._plan.copy_launches()
             assert 0 < launches < copies                     # runs of independent halo copies share a launch
         s.set_problem(lambda b: rhs2[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
@@ -281,3 +281,49 @@ def test_plan_copy_batching_keeps_sequential_semantics(seed):
     for got, want in zip(arrays, ref):
         assert torch.equal(got, want)
     plan.close()
+
+
+@pytest.mark.parametrize("px,py", [(2, 2), (2, 1)])
+def test_adaptive_policy_over_two_decomposed_solvers_native_equals_python(px, py):
+    """bench.py --gpus N in miniature: the adaptive policy drives an fp32 (managed) and an fp64 decomposed solver through
+    take_iterate_from; with recorded cycle plans -- front part of the next cycle queued before the norm arrives, dropped at
+    the precision switch, norms collected late, a second solve on the same solvers -- the trajectory, the norms and the
+    iterate equal the Python driver's without plans, bit for bit, whether or not the policy's switch is predicted."""
+    import torch
+    n = 513
+    NX, NY = px * (n - 1) + 1, py * (n - 1) + 1
+    dom = (0.0, float(px), 0.0, float(py))
+    thr = 1e-3
+    out = {}
+    for native, predict in ((False, False), (True, True), (True, False)):
+        dev = torch.device("cuda", 0)
+        solvers = {"f32": D.DistributedMultigrid(NX, NY, px, py, range(px * py), D.HipOps(np.float32, dev, managed_single=True), None,
+                                                 domain=dom, smoother="jacobi", omega=0.8, agglomerate_at=129, native=native),
+                   "f64": D.DistributedMultigrid(NX, NY, px, py, range(px * py), D.HipOps(np.float64, dev), None,
+                                                 domain=dom, smoother="jacobi", omega=0.8, agglomerate_at=129, native=native)}
+        record = []
+        for solve in range(2):
+            for sv in solvers.values():
+                sv.set_problem(lambda b: D.sine_rhs_block(b, dom))
+            policy, rn = D.AdaptivePolicy(thr), solvers["f64"].residual_norm()
+            for _ in range(9):
+                had = policy.phase
+                now = policy.before_cycle(rn)
+                if now != had:
+                    solvers[now].take_iterate_from(solvers[had])
+                solvers[now].speculate = (not policy.switch_likely()) if predict else True
+                solvers[now].cycle(0)
+                rn = solvers[now].residual_norm()
+                policy.after_cycle(rn)
+                record.append((now, rn))
+        u = H.assemble(solvers[policy.phase], NX, NY, np.float64)
+        if native:
+            assert solvers["f32"].native_cycles > 0 and solvers["f64"].native_cycles > 0
+        for sv in solvers.values():
+            sv.close()
+        out[(native, predict)] = (record, u)
+    phases = [p for p, _ in out[(False, False)][0]]
+    assert "f32" in phases and "f64" in phases                       # the policy did switch
+    for key in ((True, True), (True, False)):
+        assert out[key][0] == out[(False, False)][0]
+        np.testing.assert_array_equal(out[key][1], out[(False, False)][1])
