@@ -172,6 +172,10 @@ int mg_set_stream(mg_handle* h, void* stream, int use_own);
 /* Device-to-device forms of mg_set_rhs / mg_set_solution(NULL) / mg_get_solution: (nx, ny) arrays with pitch
  * `ld`, converted to/from the handle's working precision on the handle's stream, asynchronous. */
 int mg_set_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype);
+/* the same, for a right-hand side whose BOUNDARY RING equals that of the last mg_set_rhs / mg_set_rhs_device (the coarse
+ * right-hand side of a decomposed cycle: its ring is the injected ring of f, cycle after cycle): the rings of the coarser
+ * levels and their sums are kept instead of being injected again */
+int mg_update_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype);
 int mg_zero_solution_device(mg_handle* h);
 int mg_get_solution_device(mg_handle* h, void* u_dev, int ld, int dtype);
 /* the stream all of the handle's work is queued on (a hipStream_t), for callers that bracket with events */
@@ -300,7 +304,7 @@ enum {
   MG_PLAN_GROUP_END = 8,   /* ncclGroupEnd */
   MG_PLAN_ALLGATHER = 9,   /* i: bytes per rank;  p: send, recv */
   MG_PLAN_ALLREDUCE_F64 = 10, /* i: count;  p: buffer (in place, sum) */
-  MG_PLAN_COARSE_BEGIN = 11,  /* i: ld, dtype;  p: engine handle, rhs   (stream, rhs, zero iterate) */
+  MG_PLAN_COARSE_BEGIN = 11,  /* i: ld, dtype, same_ring (mg_update_rhs_device);  p: engine handle, rhs   (stream, rhs, zero iterate) */
   MG_PLAN_COARSE_CYCLE = 12,  /* i: cycles;  p: engine handle */
   MG_PLAN_COARSE_END = 13,    /* i: ld, dtype;  p: engine handle, out */
   MG_PLAN_EVENT_RECORD = 14,  /* i: event id (0..7) on the operation's stream */

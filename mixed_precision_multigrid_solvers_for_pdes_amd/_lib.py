@@ -101,6 +101,7 @@ SIGNATURES = {
     "mg_dev_prolong_add": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mg_set_stream": (_i, [_vp, _vp, _i]),
     "mg_set_rhs_device": (_i, [_vp, _vp, _i, _i]),
+    "mg_update_rhs_device": (_i, [_vp, _vp, _i, _i]),
     "mg_zero_solution_device": (_i, [_vp]),
     "mg_get_solution_device": (_i, [_vp, _vp, _i, _i]),
     "mg_dev_convert": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -400,7 +400,7 @@ int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
       case MG_PLAN_COARSE_BEGIN: {
         mg_handle* h = static_cast<mg_handle*>(o.p[0]);
         int rc = mg_set_stream(h, s, 0);
-        if (rc == MG_OK) rc = mg_set_rhs_device(h, o.p[1], i[0], i[1]);
+        if (rc == MG_OK) rc = i[2] ? mg_update_rhs_device(h, o.p[1], i[0], i[1]) : mg_set_rhs_device(h, o.p[1], i[0], i[1]);
         if (rc == MG_OK) rc = mg_zero_solution_device(h);
         if (rc != MG_OK) return plan_fail(&p->err, rc, std::string("coarse begin: ") + mg_last_error(h));
         break;

@@ -1583,6 +1583,22 @@ int mg_set_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype) {
   return MG_OK;
 }
 
+int mg_update_rhs_device(mg_handle* h, const void* rhs_dev, int ld, int dtype) {
+  if (!h || !rhs_dev || !valid_dtype(dtype) || ld < h->lv[0].ny) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_update_rhs_device: bad argument");
+  if (!h->have_rhs) return fail(&h->err, MG_ERR_STATE, "mg_update_rhs_device before mg_set_rhs / mg_set_rhs_device");
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  Level& v = h->lv[0];
+  for (int dt = 0; dt < 2; ++dt)
+    if (v.rhs[dt]) d_convert(dtype, dt, rhs_dev, v.rhs[dt], v.nx, v.ny, ld, v.ld[dt], h->stream);
+  h->norm_partials = 0;
+  // a new right-hand side as far as cached norms go, the same one as far as the coarse rhs rings and their sums go
+  const unsigned old_gen = h->rhs_gen++;
+  for (int p = 0; p < 2; ++p)
+    if (h->rings_gen[p] == old_gen) h->rings_gen[p] = h->rhs_gen;
+  HIPC(&h->err, hipGetLastError());
+  return MG_OK;
+}
+
 int mg_zero_solution_device(mg_handle* h) {
   if (!h) return fail(nullptr, MG_ERR_INVALID_VALUE, "NULL handle");
   HIPC(&h->err, hipSetDevice(h->cfg.device));

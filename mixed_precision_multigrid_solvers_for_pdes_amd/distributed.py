@@ -149,6 +149,7 @@ class HipOps:
         self.scratch = torch.zeros(2048, dtype=torch.float64, device=device)          # grown per field shape (_scratch_for)
         self.acc = torch.zeros(1, dtype=torch.float64, device=device)
         self._engine = None
+        self._coarse_ring_valid = False # the replicated engine holds the boundary ring of the current problem's coarse rhs
         self.rec = None                 # dist_plan.PlanRecorder while a cycle is being recorded
 
     def _stream(self):
@@ -266,13 +267,19 @@ class HipOps:
         """vertex values of the diffusion coefficient on the agglomeration level (host array; None: constant)"""
         self._engine.set_coefficient(a_host)
 
-    def coarse_begin(self, rhs_global):
+    def coarse_begin(self, rhs_global, same_ring=False):
+        """same_ring: the boundary ring of rhs_global equals that of the previous call (the coarse right-hand side of a
+        decomposed cycle: its ring is the injected ring of f, the same cycle after cycle) -- the replicated engine keeps the
+        rings of its coarser levels instead of injecting them again (mg_update_rhs_device)."""
         e = self._engine
+        same_ring = bool(same_ring) and self._coarse_ring_valid
         _lib.check(self.lib.mg_set_stream(e._h, self._stream(), 0))
-        _lib.check(self.lib.mg_set_rhs_device(e._h, self._p(rhs_global), rhs_global.stride(0), self._code(rhs_global)))
+        fn = self.lib.mg_update_rhs_device if same_ring else self.lib.mg_set_rhs_device
+        _lib.check(fn(e._h, self._p(rhs_global), rhs_global.stride(0), self._code(rhs_global)))
+        self._coarse_ring_valid = True
         _lib.check(self.lib.mg_zero_solution_device(e._h))
         if self.rec is not None:
-            self.rec.emit(_lib.MG_PLAN_COARSE_BEGIN, i=(rhs_global.stride(0), self._code(rhs_global)), p=(e._h.value, rhs_global))
+            self.rec.emit(_lib.MG_PLAN_COARSE_BEGIN, i=(rhs_global.stride(0), self._code(rhs_global), int(same_ring)), p=(e._h.value, rhs_global))
 
     def coarse_cycle(self):
         self._engine.cycle(1)
@@ -581,7 +588,10 @@ class DistributedMultigrid:
         """Coarse tail: gather the coarse rhs, run the remaining levels on the single-GPU engine (on every GPU),
         take this rank's piece of the correction (ghost zone included: it is global data)."""
         self._gather_coarse_rhs()
-        self.ops.coarse_begin(self.rhs_a)
+        if self.mode == "fused" and getattr(self.ops, "plan_capable", False):
+            self.ops.coarse_begin(self.rhs_a, same_ring=True)      # the ring went in with set_problem
+        else:
+            self.ops.coarse_begin(self.rhs_a)
         for _ in range(self._reps(l)):
             self.ops.coarse_cycle()
         self.ops.coarse_end(self.e_a)
@@ -888,6 +898,11 @@ class DistributedMultigrid:
                     d.ring_sumsq = ring
                 else:
                     d.ring_sumsq.copy_(ring)           # same buffer: a recorded plan holds its pointer
+        if self.mode == "fused" and self.Ld > 0 and getattr(self.ops, "plan_capable", False):
+            # the boundary ring of the gathered coarse rhs is final now (its interior is rewritten every cycle): the
+            # replicated engine takes it -- and the rings of its own coarser levels -- once per problem
+            self._gather_coarse_rhs()
+            self.ops.coarse_begin(self.rhs_a, same_ring=False)
         self._last_norm_parts = None
         self._norm_value = None
 
