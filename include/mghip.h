@@ -83,7 +83,7 @@ typedef struct mg_config {
                                 two launches per level, identical arithmetic) with the iterate tiled through LDS; 2: the same
                                 legs register-blocked (iterate in registers, DPP lateral neighbours) on levels above ~1100^2
                                 cells, LDS-tiled below; 3: register-blocked on every level (tests) */
-  int32_t tail;              /* with fused = 1 -- 1: all levels of <= ~65^2 cells incl. the coarsest solve run in ONE
+  int32_t tail;              /* with fused = 1 -- 1: all levels of <= ~33^2 (fp64) / ~65^2 (fp32) cells incl. the coarsest solve run in ONE
                                 workgroup with their fields in LDS (one launch per visit); 0: per-level launches */
   int32_t fmg_cycles;        /* > 0: mg_solve without an initial guess starts from a full-multigrid guess with this many
                                 cycles per level (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:583-652) */

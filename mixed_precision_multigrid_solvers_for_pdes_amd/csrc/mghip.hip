@@ -897,10 +897,16 @@ int plan_tail(mg_handle* h) {
   const int L = h->L();
   if (!h->fused() || L < 3 || h->cfg.pre > 8 || h->cfg.post > 8) return MG_OK;
   const size_t esz_last = esize(h->grid_dtype);
+  static const int max_top = [] { const char* e = std::getenv("MG_EXP_TAIL_MAXN"); return e ? std::atoi(e) : 0; }();   // experiment: largest top level
   for (int k = 1; k <= L - 2; ++k) {
     if (L - k > mg::kTailMaxLevels) continue;
     const size_t esz = (h->cfg.precision == MG_PREC_ADAPTIVE) ? 8 : esize(h->level_dtype_in(k, MG_F64));
     if (tail_pool_bytes(h, k, esz, esz_last) > kTailPoolLimit) continue;
+    // A 65^2 fp64 level costs more as two stages of the one-workgroup tail (12 us: five LDS reads per cell and stage through
+    // one CU's LDS) than as two launches of its own (2 x 4.8 us): fp64 tails start at 33^2 (bench step -8 us, W(2,2) -3 %,
+    // config 1 / 2 -10 / -6 %; profiles/README.md).  fp32 levels move half the bytes and stay in the tail from 65^2.
+    const int cap = max_top > 0 ? max_top : (esz == 8 ? 33 : 65);
+    if (std::max(h->lv[k].nx, h->lv[k].ny) > cap) continue;
     bool uniform = true;
     for (int l = k; l <= L - 2; ++l) uniform = uniform && (h->level_dtype_in(l, MG_F64) == h->level_dtype_in(k, MG_F64));
     if (!uniform) continue;
