@@ -91,7 +91,7 @@ inline Coef coefs(double hx, double hy, double sigma = 0.0) {
 // its own (shorter) tile height; fp64 tiles are the narrowest (64 columns).
 inline size_t max_partials(int nx, int ny) {
   const long long tj = (ny + 63) / 64 + 1;
-  const int ti_min = std::min(mg::kTI, std::min(mg::kFusedTI, mg::kFusedTISmall));
+  const int ti_min = std::min(mg::kTI, std::min(mg::kFusedTI, std::min(mg::kFusedTISmall, mg::kFusedTITiny)));
   const long long ti = (nx + ti_min - 1) / ti_min + 1;
   return (size_t)std::max<long long>(2048, ti * tj);
 }
@@ -380,6 +380,11 @@ inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
 inline bool small_tiles(const LegGeom& g, int sm = mg::kSmJacobi) {
   return (long long)g.nx * g.ny <= 1100LL * 1100LL || (g.acoef && sm == mg::kSmRbgs);
 }
+// 8-row tiles: constant-coefficient legs on levels of <= ~300^2 cells (MG_EXP_TINY=0 keeps the 16-row tiles: experiments)
+inline bool tiny_tiles(const LegGeom& g) {
+  static const bool on = [] { const char* e = std::getenv("MG_EXP_TINY"); return !e || std::atoi(e) != 0; }();
+  return on && !g.acoef && (long long)g.nx * g.ny <= 300LL * 300LL;
+}
 
 template <typename T, typename TX, int SM, int TI>
 void launch_down_ti(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
@@ -401,7 +406,8 @@ void launch_down_ti(const void* u, const void* rhs, void* out, void* rhs_c, cons
 }
 template <typename T, typename TX, int SM>
 void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
-  if (small_tiles(g, SM)) launch_down_ti<T, TX, SM, mg::kFusedTISmall>(u, rhs, out, rhs_c, g, zero_init, st);
+  if (tiny_tiles(g)) launch_down_ti<T, TX, SM, mg::kFusedTITiny>(u, rhs, out, rhs_c, g, zero_init, st);
+  else if (small_tiles(g, SM)) launch_down_ti<T, TX, SM, mg::kFusedTISmall>(u, rhs, out, rhs_c, g, zero_init, st);
   else launch_down_ti<T, TX, SM, mg::kFusedTI>(u, rhs, out, rhs_c, g, zero_init, st);
 }
 
@@ -437,6 +443,7 @@ int launch_up_ti(const void* u, const void* rhs, void* out, const void* e_c, dou
 template <typename T, typename TX, typename TC, int SM>
 int launch_up(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm,
               hipStream_t st) {
+  if (tiny_tiles(g)) return launch_up_ti<T, TX, TC, SM, mg::kFusedTITiny>(u, rhs, out, e_c, partials, g, norm, st);
   return small_tiles(g, SM) ? launch_up_ti<T, TX, TC, SM, mg::kFusedTISmall>(u, rhs, out, e_c, partials, g, norm, st)
                         : launch_up_ti<T, TX, TC, SM, mg::kFusedTI>(u, rhs, out, e_c, partials, g, norm, st);
 }
@@ -456,7 +463,8 @@ void launch_sweeps_ti(const void* u, const void* rhs, void* out, const LegGeom& 
 }
 template <typename T, int SM>
 void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
-  if (small_tiles(g, SM)) launch_sweeps_ti<T, SM, mg::kFusedTISmall>(u, rhs, out, g, st);
+  if (tiny_tiles(g)) launch_sweeps_ti<T, SM, mg::kFusedTITiny>(u, rhs, out, g, st);
+  else if (small_tiles(g, SM)) launch_sweeps_ti<T, SM, mg::kFusedTISmall>(u, rhs, out, g, st);
   else launch_sweeps_ti<T, SM, mg::kFusedTI>(u, rhs, out, g, st);
 }
 
