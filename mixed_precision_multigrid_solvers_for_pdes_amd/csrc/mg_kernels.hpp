@@ -1257,7 +1257,10 @@ __global__ __launch_bounds__(kBlock) void inject_kernel(const TIN* __restrict__ 
 // times.  Here the whole sub-cycle is one launch that interprets a host-built schedule of
 // {down leg, coarsest solve, up leg} steps.  Arithmetic per cell is identical to the per-operator kernels.
 // ============================================================================================
-constexpr int kTailBlock = 1024;
+#ifndef MG_TAIL_BLOCK
+#define MG_TAIL_BLOCK 1024
+#endif
+constexpr int kTailBlock = MG_TAIL_BLOCK;
 constexpr int kTailMaxLevels = 6;
 constexpr int kTailDown = 0, kTailSolve = 1, kTailUp = 2;
 
