@@ -107,6 +107,7 @@ struct mg_plan {
   hipEvent_t ev[8] = {};
   double* result_dev = nullptr;
   double* result_host = nullptr;       // pinned
+  hipEvent_t fence[2] = {};            // compute -> communication stream and back, around RCCL calls recorded on the compute stream
   hipEvent_t done = nullptr;           // recorded behind the copy of the RESULT
   bool pending = false;                // a RESULT is in flight (mg_plan_run_async) and not collected yet (mg_plan_wait)
   std::string err;
@@ -299,6 +300,10 @@ int mg_plan_create(const mg_plan_op* ops, int n_ops, void* comm, int device, mg_
     e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
   }
+  for (auto& ev : p->fence) {
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+  }
   e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
   if (e != hipSuccess) { mg_plan_destroy(p); return plan_fail(nullptr, MG_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
   e = hipHostMalloc(reinterpret_cast<void**>(&p->result_host), sizeof(double), hipHostMallocDefault);
@@ -327,6 +332,8 @@ int mg_plan_destroy(mg_plan* p) {
   if (!p) return MG_OK;
   for (auto& ev : p->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : p->fence)
+    if (ev) (void)hipEventDestroy(ev);
   if (p->done) (void)hipEventDestroy(p->done);
   if (p->result_host) (void)hipHostFree(p->result_host);
   delete p;
@@ -344,9 +351,23 @@ int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
     const char* m = mg_last_error(nullptr);
     return plan_fail(&p->err, rc, "plan op " + std::to_string(k) + " (" + what + "): " + (m ? m : ""));
   };
+  // Every RCCL call of this process on this communicator goes to ONE stream -- the communication stream -- whatever stream it
+  // was recorded on (what torch.distributed does with its own stream): a call recorded on the compute stream is fenced in
+  // and out with two events, so successive collectives never reach the communicator from two streams.
+  bool redirected = false;
+  int group_depth = 0;
   for (size_t k = 0; k < p->ops.size(); ++k) {
     const mg_plan_op& o = p->ops[k];
     hipStream_t s = st[o.stream];
+    const bool comm_op = needs_comm(o.op);
+    if (comm_op && o.stream == 0 && st[0] != st[1]) {
+      if (!redirected) {
+        PLAN_HIP(p, hipEventRecord(p->fence[0], st[0]));
+        PLAN_HIP(p, hipStreamWaitEvent(st[1], p->fence[0], 0));
+        redirected = true;
+      }
+      s = st[1];
+    }
     const int32_t* i = o.i;
     switch (o.op) {
       case MG_PLAN_DOWN_LEG: {
@@ -429,6 +450,13 @@ int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
         break;
       default:
         return plan_fail(&p->err, MG_ERR_INVALID_VALUE, "unknown plan operation");
+    }
+    if (o.op == MG_PLAN_GROUP_BEGIN) ++group_depth;
+    if (o.op == MG_PLAN_GROUP_END) --group_depth;
+    if (redirected && comm_op && group_depth == 0) {        // the call (or the whole group) is queued: hand back to the compute stream
+      PLAN_HIP(p, hipEventRecord(p->fence[1], st[1]));
+      PLAN_HIP(p, hipStreamWaitEvent(st[0], p->fence[1], 0));
+      redirected = false;
     }
   }
   PLAN_HIP(p, hipGetLastError());

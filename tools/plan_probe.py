@@ -28,9 +28,10 @@ def rccl_selftest():
     rec.result(out)
     plan = P.CyclePlan(rec, comm, 0)
     s = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()              # a communication stream of its own: the calls recorded on the compute stream are fenced over to it
     for k in range(3):
         dst.zero_(); gat.zero_()
-        v = plan.run(s, s)
+        v = plan.run(s, side.cuda_stream if k else s)
         torch.cuda.synchronize()
         assert v == 3.75, v
         assert torch.equal(dst, src) and torch.equal(gat, src)
