@@ -1632,7 +1632,7 @@ constexpr int kFusedBlock = MG_FUSED_BLOCK;      // threads of a fused-leg workg
 constexpr int kFusedTI = MG_FUSED_TI;      // tile rows of the fused legs on large levels (even: coarse rows sit on every other tile row)
 constexpr int kFusedTISmall = 16;          // ... on levels of <= ~1025^2 cells: twice the workgroups, half the critical path of a launch
                                            // that is latency-bound anyway (4.4 vs 5.7 us per leg at 129^2-513^2)
-constexpr int kFusedTITiny = 8;            // ... on levels of <= ~300^2 cells (257^2, 129^2, 65^2): a launch there is one chain of load -> stages ->
+constexpr int kFusedTITiny = 8;            // ... on levels of <= ~520^2 cells (513^2 ... 65^2): a launch there is one chain of load -> stages ->
                                            // store per workgroup; shorter tiles shorten the chain (constant-coefficient legs)
 constexpr int kPostNone = 0, kPostRestrict = 1, kPostNorm = 2;
 

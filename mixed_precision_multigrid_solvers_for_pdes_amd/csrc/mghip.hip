@@ -380,9 +380,9 @@ inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
 inline bool small_tiles(const LegGeom& g, int sm = mg::kSmJacobi) {
   return (long long)g.nx * g.ny <= 1100LL * 1100LL || (g.acoef && sm == mg::kSmRbgs);
 }
-// 8-row tiles: constant-coefficient legs on levels of <= ~300^2 cells (MG_EXP_TINY=n: up to n^2 cells, 0 keeps the 16-row tiles: experiments)
+// 8-row tiles: constant-coefficient legs on levels of <= ~520^2 cells (513^2 and below) (MG_EXP_TINY=n: up to n^2 cells, 0 keeps the 16-row tiles: experiments)
 inline bool tiny_tiles(const LegGeom& g) {
-  static const long long lim = [] { const char* e = std::getenv("MG_EXP_TINY"); return e ? (long long)std::atoi(e) : 300LL; }();   // 0: off
+  static const long long lim = [] { const char* e = std::getenv("MG_EXP_TINY"); return e ? (long long)std::atoi(e) : 520LL; }();   // 0: off
   return lim > 0 && !g.acoef && (long long)g.nx * g.ny <= lim * lim;
 }
 
