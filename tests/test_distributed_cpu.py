@@ -293,6 +293,27 @@ def test_adaptive_policy_host_port():
     assert not D.stagnating([1.0, 0.1, 0.01, 0.001, 0.0001]) and D.stagnating([1.0, 1.0, 1.0, 1.0, 1.0])
 
 
+def test_adaptive_policy_predicts_its_own_switch():
+    """switch_likely(): asked BEFORE a cycle whether the norm that cycle will produce changes the precision (the decomposed
+    driver then does not queue the next cycle's front part behind it).  On the bench trajectory it fires exactly once -- for
+    the fifth fp32 cycle, whose norm fills the stagnation window --, on a healthy contraction exactly for the cycle that
+    takes the norm below 10 thr, never in double and never after the promotion."""
+    def run(thr, norms):
+        p, fired, rn = D.AdaptivePolicy(thr), [], norms[0]
+        for k, nxt in enumerate(norms[1:]):
+            p.before_cycle(rn)
+            fired.append(p.switch_likely())
+            rn = nxt
+            p.after_cycle(rn)
+        return p, fired
+    # the 4097^2 bench problem: fp32 stagnates at ~1.8, promotion on the fifth norm
+    p, fired = run(1e-6, [13.96, 2.150, 1.808, 1.803, 1.806, 1.809, 8.5e-2, 1.0e-2, 1.4e-3])
+    assert fired == [False, False, False, False, True, False, False, False] and p.promoted
+    # healthy contraction by 0.1 per cycle towards 10 thr = 1e-2
+    p, fired = run(1e-3, [50.0, 5.0, 0.5, 0.05, 0.005, 5e-4, 5e-5])
+    assert fired == [False, False, False, True, False, False] and p.promoted and p.phase == "f64"
+
+
 def test_bench_py_gpus_2_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher (how the driver's scaling run may start it): the parent spawns the
     two ranks, waits and relays rank 0's ONE JSON line.  Rehearsed on CPU over gloo with the NumPy stand-in kernels
