@@ -105,22 +105,56 @@ def floor_of(hist):
     return floor, first_below(hist, 2.0 * floor)
 
 
+def supervise(commands, poll_s=0.2, grace_s=5.0):
+    """Run the rank processes to the end: commands = [(argv, env), ...]; rank 0's stdout is captured (through a temporary
+    file, so a long line cannot block it), the others' is dropped.  As soon as ONE rank exits non-zero the remaining ranks
+    are terminated (SIGTERM, then SIGKILL after `grace_s`): a rank whose peer died would otherwise wait for it in a
+    collective until somebody kills the job.  Returns (exit codes, rank-0 stdout)."""
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r, (argv, env) in enumerate(commands):
+            procs.append(subprocess.Popen(argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+        failed = False
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                failed = True
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(poll_s)
+        if failed:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + grace_s
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        codes = [p.wait() for p in procs]
+        out0.seek(0)
+        return codes, out0.read()
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has made
-    no GPU call and makes none), wait for all, relay rank 0's JSON line, fail if any rank fails."""
+    no GPU call and makes none), supervise them (a failing rank takes the others down), relay rank 0's JSON line, fail if
+    any rank fails."""
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    procs = []
+    commands = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
+        commands.append(([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env))
+    codes, out0 = supervise(commands)
     line = None
     for ln in (out0 or "").splitlines():
         ln = ln.strip()

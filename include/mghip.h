@@ -83,8 +83,11 @@ typedef struct mg_config {
                                 two launches per level, identical arithmetic) with the iterate tiled through LDS; 2: the same
                                 legs register-blocked (iterate in registers, DPP lateral neighbours) on levels above ~1100^2
                                 cells, LDS-tiled below; 3: register-blocked on every level (tests) */
-  int32_t tail;              /* with fused = 1 -- 1: all levels of <= ~33^2 (fp64) / ~65^2 (fp32) cells incl. the coarsest solve run in ONE
-                                workgroup with their fields in LDS (one launch per visit); 0: per-level launches */
+  int32_t tail;              /* with fused >= 1 -- 1: the coarse levels incl. the coarsest solve run in ONE workgroup per visit: the
+                                dyadic square levels 65^2 / 33^2 / 17^2 / 9^2 / 5^2 of a constant-coefficient hierarchy with
+                                iterate and rhs in REGISTERS (csrc/mg_tail_kernels.hpp), any other <= ~33^2 (fp64) / ~65^2 (fp32)
+                                sub-hierarchy with its fields in LDS; 2: the LDS kernel only; 0: per-level launches.  Same
+                                arithmetic per cell in all three */
   int32_t fmg_cycles;        /* > 0: mg_solve without an initial guess starts from a full-multigrid guess with this many
                                 cycles per level (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:583-652) */
   int32_t speculate;         /* with fused = 1 -- 1: mg_iterate / mg_solve queue the down leg of cycle k+1 while ||r_k||
@@ -93,7 +96,10 @@ typedef struct mg_config {
                                 directly (u = A^-1 f, the inverse formed on the host) instead of by the reference's Gauss-Seidel
                                 iteration to coarse_tol (solvers/multigrid.py:119-124, 355-370).  NOT bit-identical to the
                                 reference: the two differ by at most ||A_c^-1|| coarse_tol / h_c ~ 2e-13 per coarsest visit (the
-                                error the iteration is allowed to leave); off by default, a W-cycle speed option */
+                                error the iteration is allowed to leave; iterates stay within 1e-12 relative l-inf of the
+                                reference's).  0: always the iteration (bit-identical).  < 0 (the host side's default): direct
+                                in W- and F-cycles, whose 2^(L-1) coarsest visits per cycle are mostly that iteration, the
+                                iteration in V-cycles */
   int32_t mixed_split;       /* MG_PREC_MIXED_LEVELS: first fp32 level; <= 0: num_levels / 2 (core/precision.py:351-357).
                                 Set by a caller whose handle is the lower part of a longer hierarchy (distributed.py: the
                                 replicated coarse levels below the decomposed ones keep the GLOBAL split) */
@@ -330,6 +336,18 @@ int mg_plan_wait(mg_plan* plan, double* result);
 int mg_plan_num_ops(const mg_plan* plan, int* n);
 /* COPY2D operations of the plan and the launches they run as (runs of independent copies share one launch) */
 int mg_plan_copy_launches(const mg_plan* plan, int* n_copies, int* n_launches);
+/* Per-phase device times of a plan (diagnostics, outside any timed region): while enabled, every operation of mg_plan_run /
+ * mg_plan_run_async is bracketed by a pair of timing events on the stream it runs on.  mg_plan_phase_times waits for the
+ * recorded work and ADDS the elapsed milliseconds per phase to out[MG_PLAN_PHASES], then forgets the events:
+ *   [0] fused legs  [1] halo pack / unpack / scatter copies  [2] send/recv groups (includes the wait for the peers)
+ *   [3] coarse all-gather  [4] replicated coarse engine  [5] norm adds + all-reduce  [6] anything else */
+#define MG_PLAN_PHASES 7
+int mg_plan_profile(mg_plan* plan, int enable);
+int mg_plan_phase_times(mg_plan* plan, double* out_ms);
+/* MG_ERR_TIMEOUT from mg_plan_wait / mg_plan_run: the RESULT did not arrive within MG_PLAN_TIMEOUT_S seconds (environment,
+ * default 120; plans with a communicator, and any plan when the variable is set).  The queued work is NOT cancelled: the
+ * caller must not synchronise on those streams again -- a rank in this state reports and leaves the process. */
+#define MG_ERR_TIMEOUT (-6)
 const char* mg_plan_error(const mg_plan* plan);   /* NULL plan: the last mg_comm_* / mg_plan_create error of this thread */
 int mg_plan_destroy(mg_plan* plan);
 /* RCCL through the library the process already uses (`rccl_library`: path of librccl.so, e.g. torch's own copy).
@@ -337,6 +355,8 @@ int mg_plan_destroy(mg_plan* plan);
 int mg_comm_unique_id(const char* rccl_library, void* id128);
 int mg_comm_init(const char* rccl_library, const void* id128, int nranks, int rank, int device, void** comm);
 int mg_comm_destroy(void* comm);
+/* ranks of the communicator / this process's rank in it (what the bench line reports as ranks_seen) */
+int mg_comm_ranks(void* comm, int* nranks, int* rank);
 
 #ifdef __cplusplus
 }

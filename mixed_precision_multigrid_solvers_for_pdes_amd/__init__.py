@@ -12,9 +12,12 @@ from .operators import (BaseOperator, DiffusionOperator, HelmholtzOperator, Lapl
 from .precision import PrecisionLevel, PrecisionManager
 from .smoothers import (BaseSolver, ConvergenceHistory, EnhancedJacobiSolver, GaussSeidelSmoother,
                         IterativeSolver, JacobiSmoother, WeightedJacobiSmoother)
-from .solver import GPUMultigridSolver, MultigridCycle, MultigridSolver
+from .solver import GPUCommunicationAvoidingMultigrid, GPUMultigridSolver, MultigridCycle, MultigridSolver
 from .engine import MultigridEngine
 from .gpu_kernels import MixedPrecisionKernels, SmoothingKernels, TransferKernels
+from .gpu_precision import GPUPrecisionLevel, GPUPrecisionManager
+from .memory_manager import GPUMemoryManager, GPUMemoryPool
+from .multi_gpu import DecompositionType, DistributedMultigridSolver, MultiGPUManager, MultiGPUSolver
 from .facade import MixedPrecisionMultigrid, PoissonProblem, default_max_levels
 from . import applications, heat_equation
 from .heat_equation import HeatEquationConfig, HeatEquationSolver, TimeSteppingScheme
@@ -24,7 +27,9 @@ __all__ = [
     "Grid", "BaseOperator", "LaplacianOperator", "DiffusionOperator", "HelmholtzOperator", "RestrictionOperator", "ProlongationOperator",
     "PrecisionLevel", "PrecisionManager", "BaseSolver", "ConvergenceHistory", "IterativeSolver",
     "JacobiSmoother", "WeightedJacobiSmoother", "EnhancedJacobiSolver", "GaussSeidelSmoother",
-    "MultigridSolver", "GPUMultigridSolver", "MultigridCycle", "MultigridEngine",
+    "MultigridSolver", "GPUMultigridSolver", "GPUCommunicationAvoidingMultigrid", "MultigridCycle", "MultigridEngine",
+    "GPUPrecisionManager", "GPUPrecisionLevel", "GPUMemoryManager", "GPUMemoryPool",
+    "DistributedMultigridSolver", "MultiGPUSolver", "MultiGPUManager", "DecompositionType",
     "SmoothingKernels", "TransferKernels", "MixedPrecisionKernels",
     "MixedPrecisionMultigrid", "PoissonProblem", "default_max_levels",
     "PoissonSolver2D", "MultigridPreconditioner", "applications", "heat_equation", "HeatEquationSolver",

@@ -8,7 +8,14 @@ import numpy as np
 from . import _build
 
 MG_OK = 0
-MG_ERR_INVALID_VALUE, MG_ERR_NO_DEVICE, MG_ERR_HIP, MG_ERR_STATE, MG_ERR_ALLOC = -1, -2, -3, -4, -5
+MG_ERR_INVALID_VALUE, MG_ERR_NO_DEVICE, MG_ERR_HIP, MG_ERR_STATE, MG_ERR_ALLOC, MG_ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
+MG_PLAN_PHASES = 7
+PLAN_PHASE_NAMES = ("legs", "halo_copy", "halo_exchange", "coarse_allgather", "replicated_engine", "allreduce", "other")
+
+
+class PlanTimeout(RuntimeError):
+    """mg_plan_wait gave up (MG_ERR_TIMEOUT): the queued device work is still queued, so the process must not
+    synchronise on it again -- report and leave (distributed.bench_main does, with os._exit)."""
 MG_F32, MG_F64 = 0, 1
 MG_JACOBI, MG_RBGS, MG_LEXGS = 0, 1, 2
 MG_CYCLE_V, MG_CYCLE_W, MG_CYCLE_F = 0, 1, 2
@@ -118,6 +125,9 @@ SIGNATURES = {
     "mg_plan_wait": (_i, [_vp, _pd]),
     "mg_plan_num_ops": (_i, [_vp, _pi]),
     "mg_plan_copy_launches": (_i, [_vp, _pi, _pi]),
+    "mg_plan_profile": (_i, [_vp, _i]),
+    "mg_plan_phase_times": (_i, [_vp, _pd]),
+    "mg_comm_ranks": (_i, [_vp, _pi, _pi]),
     "mg_plan_error": (C.c_char_p, [_vp]),
     "mg_plan_destroy": (_i, [_vp]),
     "mg_comm_unique_id": (_i, [C.c_char_p, _vp]),
@@ -217,6 +227,8 @@ def check_plan(rc, plan=None):
     msg = (msg.decode() if msg else "") or f"mghip plan error {rc}"
     if rc == MG_ERR_INVALID_VALUE:
         raise ValueError(msg)
+    if rc == MG_ERR_TIMEOUT:
+        raise PlanTimeout("mghip: " + msg)
     raise RuntimeError("mghip: " + msg)
 
 

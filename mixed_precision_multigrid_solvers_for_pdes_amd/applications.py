@@ -22,7 +22,7 @@ from .engine import MultigridEngine
 from .grid import Grid
 from .operators import LaplacianOperator, ProlongationOperator, RestrictionOperator
 from .smoothers import GaussSeidelSmoother, JacobiSmoother
-from .solver import GPUMultigridSolver, MultigridSolver
+from .solver import GPUCommunicationAvoidingMultigrid, GPUMultigridSolver, MultigridSolver
 
 logger = logging.getLogger(__name__)
 
@@ -49,14 +49,20 @@ class PoissonSolver2D:
         self.max_iterations, self.tolerance = max_iterations, tolerance
         self.cycle_type, self.use_gpu, self.device_id = cycle_type, use_gpu, device_id
         self.enable_mixed_precision = enable_mixed_precision
-        self.solver = GPUMultigridSolver(device_id=device_id, max_levels=max_levels, max_iterations=max_iterations,
-                                         tolerance=tolerance, cycle_type=cycle_type, smoother=smoother,
-                                         enable_mixed_precision=enable_mixed_precision)
+        self.solver = self._create_solver(smoother)
         self.operator = LaplacianOperator(coefficient=-1.0)
         self.restriction = RestrictionOperator("full_weighting")
         self.prolongation = ProlongationOperator("bilinear")
         self.current_problem = None
         self.solve_history: List[Dict[str, Any]] = []
+
+    def _create_solver(self, smoother="jacobi"):                                          # poisson_solver.py:88-116
+        kw = dict(device_id=self.device_id, max_levels=self.max_levels, max_iterations=self.max_iterations,
+                  tolerance=self.tolerance, cycle_type=self.cycle_type, smoother=smoother,
+                  enable_mixed_precision=self.enable_mixed_precision)
+        if self.solver_type == "gpu_ca_multigrid":
+            return GPUCommunicationAvoidingMultigrid(use_fmg=True, **kw)
+        return GPUMultigridSolver(**kw)
 
     def _boundary_guess(self, grid, bc):
         """Dirichlet data -> boundary ring of the initial guess (None for homogeneous data)."""

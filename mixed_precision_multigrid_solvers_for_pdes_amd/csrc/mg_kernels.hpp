@@ -433,6 +433,7 @@ struct HostMailbox {
 // Fixed-order final reduction of the per-block partials (deterministic, one block).  It sits between two cycles on
 // the stream, so it is built for latency: 1024 threads, four independent 16-byte loads in flight per thread.
 constexpr int kReduceBlock = 1024;
+template <int TAG>       // a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(kReduceBlock) void reduce_partials_kernel(const double* __restrict__ partials, int n,
                                                                        double* __restrict__ out, HostMailbox* mailbox,
                                                                        unsigned long long seq) {
@@ -1336,6 +1337,11 @@ __device__ __forceinline__ void tail_rb_pass(T* __restrict__ u, const T* __restr
   }
 }
 
+// Timing-only switches (results are WRONG by construction with NO_LOAD / NO_COMPUTE / NO_STORE) exist in measurement
+// builds only: -DMG_EXPERIMENTS, built to a file of its own (tools/README.md).  The shipped library cannot carry them.
+#if !defined(MG_EXPERIMENTS) && (defined(MG_EXP_NO_LOAD) || defined(MG_EXP_NO_COMPUTE) || defined(MG_EXP_NO_STORE) || defined(MG_EXP_TAIL_TRACE))
+#error "MG_EXP_* switches need -DMG_EXPERIMENTS (a measurement build, never the shipped library)"
+#endif
 #ifndef MG_EXP_TAIL_TRACE
 #define MG_EXP_TAIL_TRACE 0
 #endif

@@ -110,6 +110,9 @@ struct mg_plan {
   hipEvent_t fence[2] = {};            // compute -> communication stream and back, around RCCL calls recorded on the compute stream
   hipEvent_t done = nullptr;           // recorded behind the copy of the RESULT
   bool pending = false;                // a RESULT is in flight (mg_plan_run_async) and not collected yet (mg_plan_wait)
+  bool profile = false;                // mg_plan_profile: bracket every operation with timing events
+  struct Span { int phase; hipEvent_t e0, e1; };
+  std::vector<Span> spans;             // recorded while `profile`, consumed by mg_plan_phase_times
   std::string err;
 };
 
@@ -124,6 +127,19 @@ namespace {
 
 int nccl_fail(mg_plan* p, int rc, const char* what) {
   return plan_fail(&p->err, MG_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+}
+
+// phase of an operation for mg_plan_phase_times (include/mghip.h)
+int phase_of(int op) {
+  switch (op) {
+    case MG_PLAN_DOWN_LEG: case MG_PLAN_UP_LEG: return 0;
+    case MG_PLAN_COPY2D: return 1;
+    case MG_PLAN_GROUP_BEGIN: case MG_PLAN_SEND: case MG_PLAN_RECV: case MG_PLAN_GROUP_END: return 2;
+    case MG_PLAN_ALLGATHER: return 3;
+    case MG_PLAN_COARSE_BEGIN: case MG_PLAN_COARSE_CYCLE: case MG_PLAN_COARSE_END: return 4;
+    case MG_PLAN_ADD_F64: case MG_PLAN_ALLREDUCE_F64: return 5;
+    default: return 6;
+  }
 }
 
 bool needs_comm(int op) {
@@ -328,8 +344,40 @@ int mg_plan_copy_launches(const mg_plan* plan, int* n_copies, int* n_launches) {
   return MG_OK;
 }
 
+int mg_plan_profile(mg_plan* p, int enable) {
+  if (!p) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_profile: NULL plan");
+  p->profile = enable != 0;
+  return MG_OK;
+}
+
+int mg_plan_phase_times(mg_plan* p, double* out_ms) {
+  if (!p || !out_ms) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_phase_times: NULL argument");
+  PLAN_HIP(p, hipSetDevice(p->device));
+  int rc = MG_OK;
+  for (auto& sp : p->spans) {
+    if (sp.e0 && sp.e1 && rc == MG_OK) {
+      float ms = 0.f;
+      if (hipEventSynchronize(sp.e1) != hipSuccess || hipEventElapsedTime(&ms, sp.e0, sp.e1) != hipSuccess)
+        rc = plan_fail(&p->err, MG_ERR_HIP, "mg_plan_phase_times: a timing event could not be read");
+      else out_ms[sp.phase] += ms;
+    }
+    if (sp.e0) (void)hipEventDestroy(sp.e0);
+    if (sp.e1) (void)hipEventDestroy(sp.e1);
+  }
+  p->spans.clear();
+  return rc;
+}
+
+int mg_comm_ranks(void* comm, int* nranks, int* rank) {
+  const Comm* c = static_cast<const Comm*>(comm);
+  if (!c || !nranks || !rank) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_comm_ranks: NULL argument");
+  *nranks = c->nranks; *rank = c->rank;
+  return MG_OK;
+}
+
 int mg_plan_destroy(mg_plan* p) {
   if (!p) return MG_OK;
+  for (auto& sp : p->spans) { if (sp.e0) (void)hipEventDestroy(sp.e0); if (sp.e1) (void)hipEventDestroy(sp.e1); }
   for (auto& ev : p->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : p->fence)
@@ -369,6 +417,14 @@ int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
       s = st[1];
     }
     const int32_t* i = o.i;
+    // diagnostics: a timing-event pair around the operation (a send/recv group: around the whole group) on its stream
+    const bool span_op = p->profile && o.op != MG_PLAN_EVENT_RECORD && o.op != MG_PLAN_STREAM_WAIT && o.op != MG_PLAN_RESULT;
+    hipEvent_t span_e0 = nullptr;
+    if (span_op && !(group_depth > 0)) {
+      PLAN_HIP(p, hipEventCreate(&span_e0));
+      PLAN_HIP(p, hipEventRecord(span_e0, s));
+      p->spans.push_back({phase_of(o.op), span_e0, nullptr});
+    }
     switch (o.op) {
       case MG_PLAN_DOWN_LEG: {
         const int rc = mg_dev_down_leg_var(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], o.d[0], o.d[1], o.d[2],
@@ -453,6 +509,12 @@ int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
     }
     if (o.op == MG_PLAN_GROUP_BEGIN) ++group_depth;
     if (o.op == MG_PLAN_GROUP_END) --group_depth;
+    if (span_op && group_depth == 0 && !p->spans.empty() && !p->spans.back().e1) {
+      hipEvent_t e1 = nullptr;
+      PLAN_HIP(p, hipEventCreate(&e1));
+      PLAN_HIP(p, hipEventRecord(e1, s));
+      p->spans.back().e1 = e1;
+    }
     if (redirected && comm_op && group_depth == 0) {        // the call (or the whole group) is queued: hand back to the compute stream
       PLAN_HIP(p, hipEventRecord(p->fence[1], st[1]));
       PLAN_HIP(p, hipStreamWaitEvent(st[0], p->fence[1], 0));
@@ -471,18 +533,22 @@ int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
 int mg_plan_wait(mg_plan* p, double* result) {
   if (!p) return plan_fail(nullptr, MG_ERR_INVALID_VALUE, "mg_plan_wait: NULL plan");
   if (!p->pending) return plan_fail(&p->err, MG_ERR_STATE, "mg_plan_wait: no result in flight (the plan has no RESULT, or it was already collected)");
-  if (p->comm) {
+  const char* env_limit = std::getenv("MG_PLAN_TIMEOUT_S");
+  const double env_s = env_limit ? std::atof(env_limit) : 0.0;
+  if (p->comm || env_s > 0) {
     // a plan that talks to other ranks waits with a deadline: a peer that never posts its half of an exchange must end in
-    // an error here, not in a process that hangs until somebody kills it (MG_PLAN_TIMEOUT_S, default 120 s)
-    static const double limit = [] { const char* e = std::getenv("MG_PLAN_TIMEOUT_S"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 120.0; }();
+    // an error here, not in a process that hangs until somebody kills it (MG_PLAN_TIMEOUT_S, default 120 s; when the
+    // variable is set the deadline also covers plans without a communicator).  The queued work stays queued: the caller
+    // reports and leaves the process (MG_ERR_TIMEOUT), it does not synchronise on these streams again.
+    const double limit = env_s > 0 ? env_s : 120.0;
     const auto t0 = std::chrono::steady_clock::now();
     for (long spins = 0;; ++spins) {
       const hipError_t q = hipEventQuery(p->done);
       if (q == hipSuccess) break;
       if (q != hipErrorNotReady) return plan_fail(&p->err, MG_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
-      if ((spins & 1023) == 1023 &&
+      if ((spins & 63) == 63 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
-        return plan_fail(&p->err, MG_ERR_HIP, "cycle plan: no result after MG_PLAN_TIMEOUT_S seconds (a peer rank is not taking part in an exchange?)");
+        return plan_fail(&p->err, MG_ERR_TIMEOUT, "cycle plan: no result after MG_PLAN_TIMEOUT_S seconds (a peer rank is not taking part in an exchange?)");
     }
   } else {
     PLAN_HIP(p, hipEventSynchronize(p->done));

@@ -1,6 +1,7 @@
 // libmghip.so -- C ABI (include/mghip.h) over the CDNA4 kernels in mg_kernels.hpp, plus the
 // device-resident V/W/F-cycle driver (reference: solvers/multigrid.py:184-337, gpu/gpu_solver.py:186-446).
 // No Python, no torch types: plain pointers and sizes.
+#include "mg_host.hpp"
 #include "mg_kernels.hpp"
 #include "mg_rb_kernels.hpp"
 
@@ -17,6 +18,8 @@
 #include <vector>
 
 #include "../../include/mghip.h"
+
+using namespace mgh;
 
 namespace {
 
@@ -41,9 +44,6 @@ int fail(std::string* where, int code, const std::string& msg) {
                   std::string(#call) + ": " + hipGetErrorString(e_));                              \
   } while (0)
 
-inline size_t esize(int dt) { return dt == MG_F32 ? 4 : 8; }
-inline bool valid_dtype(int dt) { return dt == MG_F32 || dt == MG_F64; }
-
 // Row pitch in elements: rows start on 512-byte boundaries (every tile row segment is line aligned).
 inline int pitch_elems(int dt, int ny) {
   const size_t bytes = ((size_t)ny * esize(dt) + 511) / 512 * 512;
@@ -66,26 +66,6 @@ mg::TileGeom make_geom(int nx, int ny, int ld, bool interior_only) {
   return g;
 }
 
-struct Coef {
-  double ihx2, ihy2, diag, invD;
-  bool pow2;       // 1/diag is exact: multiply instead of divide
-  bool all_pow2;   // hx^2, hy^2 and diag are all powers of two
-};
-// sigma: Helmholtz shift, A = coeff * (Laplacian_h - sigma I) (coeff = -1: -Laplacian + sigma); it only moves the
-// diagonal, so every constant-coefficient kernel serves the shifted operator unchanged (sigma = 0: the reference's).
-inline Coef coefs(double hx, double hy, double sigma = 0.0) {
-  Coef c;
-  c.ihx2 = 1.0 / (hx * hx);
-  c.ihy2 = 1.0 / (hy * hy);
-  c.diag = 2.0 / (hx * hx) + 2.0 / (hy * hy);   // operators/laplacian.py:76, smoothers.py:65
-  if (sigma != 0.0) c.diag += sigma;
-  c.invD = 1.0 / c.diag;
-  int e = 0;
-  c.pow2 = std::frexp(c.diag, &e) == 0.5;
-  c.all_pow2 = c.pow2 && std::frexp(hx * hx, &e) == 0.5 && std::frexp(hy * hy, &e) == 0.5;
-  return c;
-}
-
 // Upper bound of the per-workgroup partial sums any norm launch on an (nx, ny) field writes: the grid-stride
 // reductions use <= 2048 workgroups, the residual+norm kernel one per kTI-row tile, the fused up leg one per tile of
 // its own (shorter) tile height; fp64 tiles are the narrowest (64 columns).
@@ -94,20 +74,6 @@ inline size_t max_partials(int nx, int ny) {
   const int ti_min = std::min(mg::kTI, std::min(mg::kFusedTI, std::min(mg::kFusedTISmall, mg::kFusedTITiny)));
   const long long ti = (nx + ti_min - 1) / ti_min + 1;
   return (size_t)std::max<long long>(2048, ti * tj);
-}
-
-// min{x >= 0 : sqrt(x) >= tol}: "sqrt(x) < tol" and "x < sqrt_threshold(tol)" decide alike for every double x (IEEE sqrt is
-// correctly rounded, hence monotone) -- lets a latency-bound stop test skip the square root.  tol <= 0 never stops.
-inline double sqrt_threshold(double tol) {
-  if (!(tol > 0.0)) return 0.0;
-  thread_local double last_tol = -1.0, last_thr = 0.0;       // one tolerance per solver in practice: launched per tail visit
-  if (tol == last_tol) return last_thr;
-  last_tol = tol;
-  double y = tol * tol;
-  while (y > 0.0 && std::sqrt(y) >= tol) y = std::nextafter(y, 0.0);
-  while (std::sqrt(y) < tol) y = std::nextafter(y, INFINITY);
-  last_thr = y;
-  return y;
 }
 
 inline int grid_for(long long work_items) {
@@ -164,7 +130,7 @@ int launch_sumsq(const void* x, double* partials, int ld, int i_lo, int i_hi, in
 
 inline void launch_reduce(const double* partials, int n, double* out, hipStream_t st, mg::HostMailbox* mailbox = nullptr,
                           unsigned long long seq = 0) {
-  hipLaunchKernelGGL(mg::reduce_partials_kernel, dim3(1), dim3(mg::kReduceBlock), 0, st, partials, n, out, mailbox, seq);
+  hipLaunchKernelGGL(mg::reduce_partials_kernel<0>, dim3(1), dim3(mg::kReduceBlock), 0, st, partials, n, out, mailbox, seq);
 }
 
 template <typename TI, typename TO>
@@ -349,7 +315,7 @@ mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int n
   a.ci_off = a.cj_off = 0; a.sides = mg::kAllSides;
   a.ni_lo = 1; a.ni_hi = nx - 1; a.nj_lo = 1; a.nj_hi = ny - 1;
   a.select = 0; a.in_i_lo = a.in_j_lo = 0; a.in_i_hi = a.in_j_hi = 0;
-  static const int flags = [] { const char* e = std::getenv("MG_EXP_FLAGS"); return e ? std::atoi(e) : 0; }();
+  static const int flags = exp_env("MG_EXP_FLAGS", 0);          // measurement builds only (mg_host.hpp: exp_env)
   a.exp_flags = flags;
   return a;
 }
@@ -382,7 +348,7 @@ inline bool small_tiles(const LegGeom& g, int sm = mg::kSmJacobi) {
 }
 // 8-row tiles: constant-coefficient legs on levels of <= ~520^2 cells (513^2 and below) (MG_EXP_TINY=n: up to n^2 cells, 0 keeps the 16-row tiles: experiments)
 inline bool tiny_tiles(const LegGeom& g) {
-  static const long long lim = [] { const char* e = std::getenv("MG_EXP_TINY"); return e ? (long long)std::atoi(e) : 520LL; }();   // 0: off
+  static const long long lim = exp_env("MG_EXP_TINY", 520);   // 0: off
   return lim > 0 && !g.acoef && (long long)g.nx * g.ny <= lim * lim;
 }
 
@@ -485,7 +451,7 @@ inline bool use_rb(const LegGeom& g, int) { return g.rb == 2 || (g.rb == 1 && (l
 // Arrays of more than ~100 MB cannot stay in the 256 MiB Infinity Cache from one leg to the next (u, t and rhs compete):
 // their legs run with streaming hints (rb_leg_kernel TAG 2).  MG_RB_NT=0/1 overrides (experiments).
 inline bool rb_stream(const LegGeom& g, size_t esz) {
-  static const int force = [] { const char* e = std::getenv("MG_RB_NT"); return e ? std::atoi(e) : -1; }();
+  static const int force = exp_env("MG_RB_NT", -1);
   if (force >= 0) return force != 0;
   return (size_t)g.nx * g.ld * esz > (size_t)100 << 20;
 }
@@ -558,7 +524,7 @@ void launch_sweeps_rb(const void* u, const void* rhs, void* out, const LegGeom& 
 // MG_JACOBI_RB=0 keeps the LDS-tiled jacobi_kernel (A/B runs).
 bool jacobi_rb(int dt, const void* u, const void* rhs, void* out, int nx, int ny, int ld, double hx, double hy, double omega,
                hipStream_t st, double sigma) {
-  static const int on = [] { const char* e = std::getenv("MG_JACOBI_RB"); return e ? std::atoi(e) : 1; }();
+  static const int on = exp_env("MG_JACOBI_RB", 1);
   LegGeom g{nx, ny, ld, 0, 0, 0, hx, hy, omega, 0.0, 1, 0, true};
   g.sigma = sigma; g.rb = 1;
   // only where the arrays stream from HBM (4097^2 fp64: 81 -> 78 us); Infinity-Cache-resident sweeps are faster LDS-tiled
@@ -673,80 +639,7 @@ int download(std::string* err, void* host, int hdt, const void* dev, int ddt, in
   return MG_OK;
 }
 
-struct Level {
-  int nx = 0, ny = 0;
-  double hx = 0, hy = 0;
-  int ld[2] = {0, 0};
-  void* u[2] = {nullptr, nullptr};     // current iterate
-  void* t[2] = {nullptr, nullptr};     // Jacobi ping-pong partner (same boundary ring as u)
-  void* rhs[2] = {nullptr, nullptr};
-  void* r[2] = {nullptr, nullptr};     // residual
-  void* a[2] = {nullptr, nullptr};     // diffusion coefficient (variable-coefficient operator), else null
-  double timings[3] = {0, 0, 0};       // smooth / restrict / prolong seconds (cfg.profile)
-};
-
 }  // namespace
-
-struct mg_handle {
-  mg_config cfg;
-  std::vector<Level> lv;
-  hipStream_t stream = nullptr;
-  hipStream_t own_stream = nullptr;   // created by mg_create; `stream` may be redirected by mg_set_stream
-  double* partials = nullptr;   // device: one fp64 partial per workgroup of the largest reduction (sized in mg_create)
-  double* d_scalar = nullptr;   // device, one double
-  int* d_int = nullptr;         // device, one int (coarse sweeps)
-  double* h_scalar = nullptr;   // pinned host
-  int* h_int = nullptr;         // pinned host
-  mg::HostMailbox* mbox = nullptr;       // pinned, mapped: the norm of every iteration arrives here
-  mg::HostMailbox* mbox_dev = nullptr;   // its device-side address
-  unsigned long long mbox_seq = 0;
-  void* staging = nullptr;      // fine-level sized fp64 staging for dtype-converting transfers
-  int grid_dtype = MG_F64;      // the reference Grid's dtype: MG_F32 only for MG_PREC_SINGLE
-  int phase = MG_F64;           // working precision of the adaptive policy
-  bool promoted = false;        // one-way rule: fp32 -> fp64 happened
-  bool have_rhs = false;
-  bool varcoef = false;          // A = coeff * div(a grad .) with the per-level fields lv[l].a
-  double sigma = 0.0;            // Helmholtz shift: A = coeff * (Laplacian - sigma I) on every level (mg_set_shift)
-  double ring_sumsq[2] = {0, 0};   // sum of f^2 over the boundary ring of the fine rhs, per dtype (r = f there)
-  unsigned rhs_gen = 1;            // bumped by every new right-hand side
-  unsigned rings_gen[2] = {0, 0};  // rhs_gen the coarse rhs rings of working precision p were injected for (adaptive policy)
-  bool iterate_zero = false;       // the fine iterate is zero everywhere (mg_set_solution(NULL) / mg_zero_solution_device, no cycle since)
-  unsigned zero_norm_gen[2] = {0, 0};   // ||f - A 0|| = ||f|| as the norm kernel sums it, per dtype, for right-hand side rhs_gen
-  double zero_norm_val[2] = {0, 0};
-  int norm_partials = 0;           // > 0: `partials` holds sum r^2 over interior cells of the CURRENT fine iterate
-  int tail_start = -1;             // first level of the single-workgroup LDS tail (-1: none)
-  int* d_tail_ops = nullptr;       // device copy of the tail schedule
-  int tail_nops = 0;
-  bool tail_direct = false;        // cfg.coarse_direct applies: 5 x 5 coarsest grid inside the tail; tail_minv is its inverse
-  double tail_minv[81] = {0};
-  double tail_minv_sigma = -1.0;   // the shift tail_minv was built for (rebuilt when mg_set_shift changes it)
-  std::string err;
-  std::vector<double> adapt_hist;
-
-  int L() const { return (int)lv.size(); }
-  // precision a level computes in (solvers/multigrid.py:275-285 + core/precision.py:337-357); the coarsest
-  // level is never converted by the reference (multigrid.py:270-272 returns first) and stays in the grid dtype.
-  int level_dtype_in(int l, int ph) const {
-    if (l == L() - 1) return grid_dtype;
-    switch (cfg.precision) {
-      case MG_PREC_SINGLE: return MG_F32;
-      case MG_PREC_SINGLE_MANAGED: return MG_F32;
-      case MG_PREC_DEFECT: return MG_F32;          // the error equation's hierarchy; the iterate itself is fp64 (iterate_dtype)
-      case MG_PREC_MIXED_LEVELS: return (l >= (cfg.mixed_split > 0 ? cfg.mixed_split : L() / 2)) ? MG_F32 : MG_F64;
-      case MG_PREC_ADAPTIVE: return ph;
-      default: return MG_F64;
-    }
-  }
-  int level_dtype(int l) const { return level_dtype_in(l, phase); }
-  bool fused() const { return cfg.fused != 0 && (cfg.smoother == MG_JACOBI || cfg.smoother == MG_RBGS); }
-  bool needs(int l, int dt) const {
-    if (cfg.precision == MG_PREC_ADAPTIVE) return (l == L() - 1) ? dt == grid_dtype : true;
-    if (cfg.precision == MG_PREC_DEFECT && l == 0 && dt == MG_F64) return true;      // fp64 iterate, its ping-pong partner and f
-    return level_dtype(l) == dt;
-  }
-  // precision of the fine iterate the caller sets / gets: the level-0 working precision, except for defect correction
-  int iterate_dtype() const { return cfg.precision == MG_PREC_DEFECT ? MG_F64 : level_dtype(0); }
-};
 
 namespace {
 
@@ -896,16 +789,35 @@ int tail_set_attr(size_t bytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) ? MG_OK : MG_ERR_HIP;
 }
 
+// mg_config.coarse_direct: 1 the nine unknowns of a 5 x 5 coarsest grid are solved directly, 0 by the reference's iteration
+// to coarse_tol, < 0 (default) directly in W- and F-cycles -- which visit the coarsest level 2^(L-1) times per cycle and spend
+// most of their time in that iteration -- and by the iteration in V-cycles.
+bool want_direct(const mg_handle* h) {
+  const int L = h->L();
+  if (h->lv[L - 1].nx != 5 || h->lv[L - 1].ny != 5) return false;
+  if (h->cfg.coarse_direct > 0) return true;
+  return h->cfg.coarse_direct < 0 && h->cfg.cycle != MG_CYCLE_V;
+}
+
 // Decide where the tail starts: the first level k >= 1 whose sub-hierarchy fits the LDS pool, has at most
 // kTailMaxLevels levels and (per-level MIXED policy) one dtype on levels k .. L-2.
+int plan_tail_lds(mg_handle* h);
 int plan_tail(mg_handle* h) {
+  int rc = plan_tail_lds(h);
+  if (rc != MG_OK) return rc;
+  rc = tail2_plan(h);                       // the register-resident tail takes precedence where it applies
+  if (rc == MG_OK && h->tail2_start >= 0) h->tail_direct = want_direct(h);
+  return rc;
+}
+int plan_tail_lds(mg_handle* h) {
   h->tail_start = -1;
+  h->tail2_start = -1;
   h->tail_direct = false;
   if (h->d_tail_ops) { (void)hipFree(h->d_tail_ops); h->d_tail_ops = nullptr; }      // re-planned when the operator changes
   const int L = h->L();
   if (!h->fused() || L < 3 || h->cfg.pre > 8 || h->cfg.post > 8) return MG_OK;
   const size_t esz_last = esize(h->grid_dtype);
-  static const int max_top = [] { const char* e = std::getenv("MG_EXP_TAIL_MAXN"); return e ? std::atoi(e) : 0; }();   // experiment: largest top level
+  static const int max_top = exp_env("MG_EXP_TAIL_MAXN", 0);   // experiment: largest top level
   for (int k = 1; k <= L - 2; ++k) {
     if (L - k > mg::kTailMaxLevels) continue;
     const size_t esz = (h->cfg.precision == MG_PREC_ADAPTIVE) ? 8 : esize(h->level_dtype_in(k, MG_F64));
@@ -924,7 +836,7 @@ int plan_tail(mg_handle* h) {
   h->tail_direct = false;
   h->tail_minv_sigma = -1.0;
   if (h->tail_start < 0) return MG_OK;
-  h->tail_direct = h->cfg.coarse_direct != 0 && h->lv[L - 1].nx == 5 && h->lv[L - 1].ny == 5;
+  h->tail_direct = want_direct(h);
   std::vector<int> ops;
   tail_schedule(h, h->tail_start, h->tail_start, 2, ops);
   h->tail_nops = (int)ops.size();
@@ -1045,7 +957,11 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   Level& f = h->lv[l];
   const int dt = h->level_dtype(l);
   const size_t bytes = (size_t)f.nx * f.ld[dt] * esize(dt);
-  if (l == h->tail_start && h->cfg.tail != 0) return launch_tail(h, zero_u);
+  if (l == h->tail2_start && h->cfg.tail != 0) {
+    if (h->tail_direct && h->tail_minv_sigma != h->sigma) { const int rc = build_coarse_inverse(h); if (rc != MG_OK) return rc; }
+    return tail2_launch(h, zero_u);
+  }
+  if (l == h->tail_start && h->cfg.tail != 0 && (h->tail2_start < 0 || l < h->tail2_start)) return launch_tail(h, zero_u);
   if (l == L - 1) {
     coarse_solve(h, l, zero_u);
     return MG_OK;
@@ -1150,6 +1066,27 @@ int fmg_init(mg_handle* h, int ncyc) {
 }
 
 void inject_rings_fwd(mg_handle* h);      // = inject_rings(h, h->phase), defined below
+int launch_defect(mg_handle* h, bool update);
+
+// Full-multigrid start under defect correction (MG_PREC_DEFECT): the fp32 hierarchy solves the ERROR equation, so the FMG
+// pass runs on A e = f - A u0 (u0: the Dirichlet ring of the fp64 iterate, zero inside) from the zero correction, and the
+// result is added to the fp64 iterate -- the defect loop then starts from u0 + e instead of discarding the FMG work.
+int defect_fmg(mg_handle* h, int ncyc) {
+  if (h->varcoef) return MG_ERR_INVALID_VALUE;
+  if (h->L() < 2) return MG_OK;
+  Level& v = h->lv[0];
+  (void)launch_defect(h, false);                     // rhs[fp32] = f - A u (zero ring)
+  inject_rings_fwd(h);                               // (zero) rings of every coarse rhs
+  const size_t bytes = (size_t)v.nx * v.ld[MG_F32] * 4;
+  (void)hipMemsetAsync(v.u[MG_F32], 0, bytes, h->stream);
+  if (v.t[MG_F32]) (void)hipMemsetAsync(v.t[MG_F32], 0, bytes, h->stream);
+  const int rc = fmg_init(h, ncyc);                  // e in lv[0].u[fp32]
+  if (rc != MG_OK) return rc;
+  (void)launch_defect(h, true);                      // u <- u + e in fp64 (and the next defect)
+  h->norm_partials = 0;
+  h->iterate_zero = false;
+  return MG_OK;
+}
 
 // ---- defect correction (MG_PREC_DEFECT): fp64 iterate and residual, fp32 cycles on the error equation -----------------
 // One pass over the fine grid per outer step: u <- u + e (the fp32 correction of the cycle just run), r = f - A u in
@@ -1651,6 +1588,8 @@ int mg_set_rhs(mg_handle* h, const void* rhs, int host_dtype) {
 int mg_set_coefficient(mg_handle* h, const void* a_host, int host_dtype) {
   if (!h || !valid_dtype(host_dtype)) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_coefficient: bad argument");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
+  if (a_host && h->cfg.precision == MG_PREC_DEFECT)
+    return fail(&h->err, MG_ERR_INVALID_VALUE, "mg_set_coefficient: defect correction (MG_PREC_DEFECT) runs the constant-coefficient operator");
   h->norm_partials = 0;
   if (!a_host) {                                           // back to the constant-coefficient operator
     const bool was = h->varcoef;
@@ -1712,8 +1651,10 @@ int mg_fmg(mg_handle* h, int cycles_per_level) {
   if (!h || cycles_per_level < 0) return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_fmg: bad argument");
   if (!h->have_rhs) return fail(&h->err, MG_ERR_STATE, "mg_fmg before mg_set_rhs");
   HIPC(&h->err, hipSetDevice(h->cfg.device));
-  const int rc = fmg_init(h, cycles_per_level);
-  if (rc != MG_OK) return fail(&h->err, rc, "mg_fmg: unsupported precision combination");
+  const int rc = h->cfg.precision == MG_PREC_DEFECT ? defect_fmg(h, cycles_per_level) : fmg_init(h, cycles_per_level);
+  if (rc != MG_OK) return fail(&h->err, rc, h->varcoef && h->cfg.precision == MG_PREC_DEFECT
+                                                 ? "mg_fmg: defect correction runs the constant-coefficient operator"
+                                                 : "mg_fmg: unsupported precision combination");
   return MG_OK;
 }
 
@@ -1900,7 +1841,8 @@ int mg_solve(mg_handle* h, const void* rhs, const void* u0, void* u_out, int hos
   if (rc != MG_OK) return rc;
   st.h2d_seconds = now_s() - t0;
   if (h->cfg.fmg_cycles > 0 && !u0) {                        // gpu/gpu_solver.py:583: FMG only without an initial guess
-    if ((rc = fmg_init(h, h->cfg.fmg_cycles)) != MG_OK) return fail(&h->err, rc, "fmg: unsupported precision combination");
+    rc = h->cfg.precision == MG_PREC_DEFECT ? defect_fmg(h, h->cfg.fmg_cycles) : fmg_init(h, h->cfg.fmg_cycles);
+    if (rc != MG_OK) return fail(&h->err, rc, "fmg: unsupported precision combination");
   }
   rc = iterate_impl(h, tol, max_iter, hist, hist_cap, n_iter, converged, prec_hist, &st);
   if (rc != MG_OK) return rc;
@@ -1924,8 +1866,9 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
   if ((op == 0 || op == 10) && h->cfg.smoother != MG_JACOBI) return fail(&h->err, MG_ERR_STATE, "mg_time_op: jacobi needs a Jacobi-configured handle");
   if ((op == 0 || (op >= 7 && op <= 9)) && !v.t[dt]) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no ping-pong buffer on this level");
   if ((op == 2 || op == 4 || op == 5 || op == 7 || op == 8) && (level >= h->L() - 1 || !v.r[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no coarser level");
-  static const int exp_nsweep = [] { const char* e = std::getenv("MG_EXP_NSWEEP"); return e ? std::atoi(e) : 2; }();
+  static const int exp_nsweep = exp_env("MG_EXP_NSWEEP", 2);
   h->norm_partials = 0;
+  if (level == 0 && (op == 0 || op == 1 || (op >= 5 && op <= 9))) h->iterate_zero = false;    // these rewrite the fine iterate
   // op 10: the single-sweep Jacobi kernel rotating over independent {u, rhs, out} sets whose total exceeds three
   // times the 256 MiB Infinity Cache, so that no launch finds its operands on die: the HBM-proper smoother figure
   std::vector<void*> hbm_sets;

@@ -152,6 +152,12 @@ class RcclComm:
         _lib.check_plan(self.lib.mg_comm_init(self.path, ident, 1, 0, int(device_index), C.byref(self.handle)))
         return self
 
+    def ranks(self):
+        """(ranks of the communicator, this process's rank in it)"""
+        n, r = C.c_int(0), C.c_int(0)
+        _lib.check_plan(self.lib.mg_comm_ranks(self.handle, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
     def close(self):
         if self.handle:
             self.lib.mg_comm_destroy(self.handle)
@@ -159,6 +165,18 @@ class RcclComm:
 
 
 _shared = {}
+_shared_streams = {}
+
+
+def shared_comm_stream(device):
+    """ONE communication stream per process and device, used by every solver of that process (the fp32 and the fp64 one share
+    the RCCL communicator of shared_comm, and every RCCL call on a communicator must come from one stream: with a stream per
+    solver the fp32 solver's queued front part and the fp64 plan's groups after a precision switch would reach it from two)."""
+    import torch
+    key = torch.device(device).index or 0
+    if key not in _shared_streams:
+        _shared_streams[key] = torch.cuda.Stream(device=torch.device("cuda", key))
+    return _shared_streams[key]
 
 
 def shared_comm(dist, device_index):
@@ -173,6 +191,7 @@ def shutdown():
     for c in _shared.values():
         c.close()
     _shared.clear()
+    _shared_streams.clear()
 
 
 class CyclePlan:
@@ -209,6 +228,19 @@ class CyclePlan:
         if rc != _lib.MG_OK:
             _lib.check_plan(rc, self.handle)
         return out.value
+
+    def profile(self, enable=True):
+        """bracket every operation of the coming runs with timing events (diagnostics; see phase_times)"""
+        _lib.check_plan(self.lib.mg_plan_profile(self.handle, int(bool(enable))), self.handle)
+
+    def phase_times(self, into=None):
+        """milliseconds per phase (_lib.PLAN_PHASE_NAMES) of the runs recorded since the last call, added to `into`"""
+        out = (C.c_double * _lib.MG_PLAN_PHASES)()
+        _lib.check_plan(self.lib.mg_plan_phase_times(self.handle, out), self.handle)
+        res = into if into is not None else {}
+        for k, name in enumerate(_lib.PLAN_PHASE_NAMES):
+            res[name] = res.get(name, 0.0) + out[k]
+        return res
 
     def copy_launches(self):
         """(COPY2D operations, launches they run as)"""

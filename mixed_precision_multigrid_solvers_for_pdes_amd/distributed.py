@@ -305,6 +305,38 @@ class _Dom:
     """Per-rank state: one Block per distributed level and its fields."""
 
 
+class _Phase:
+    """`with solver._ph(name):` -- adds the time of the enclosed work to solver.phase_times[name] when profiling is on"""
+
+    def __init__(self, owner, name):
+        self.o, self.name = owner, name
+
+    def __enter__(self):
+        o = self.o
+        self.on = o.phase_times is not None
+        if not self.on:
+            return self
+        self.cuda = bool(getattr(o.ops, "supports_overlap", False))        # device kernels: stream-ordered timing events
+        if self.cuda:
+            self.e0 = o.torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        else:
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if not self.on:
+            return False
+        o = self.o
+        if self.cuda:
+            e1 = o.torch.cuda.Event(enable_timing=True)
+            e1.record()
+            o._phase_events.append((self.name, self.e0, e1))
+        else:
+            o.phase_times[self.name] += (time.perf_counter() - self.t0) * 1e3
+        return False
+
+
 # Ghost width of the fused mode: the smallest odd G for which the owned cells stay exact through every fused visit.
 # With s = halo cells a leg's two sweeps consume (Jacobi 2, red-black GS 4: one per colour pass), m exact ghost cells
 # after the up leg of a level and m_c on the level below: m = min(G - s, 2 m_c - 1) - s; the recursion must reproduce
@@ -400,7 +432,10 @@ class DistributedMultigrid:
         self.overlap = bool(overlap) and self.mode == "fused" and getattr(ops, "supports_overlap", False)
         if self.overlap:
             torch = self.torch
-            self._comm_stream = torch.cuda.Stream()
+            from . import dist_plan
+            # ONE communication stream per process and device: the solvers of a process share the RCCL communicator, and every
+            # RCCL call on a communicator must reach it from one stream (dist_plan.shared_comm_stream)
+            self._comm_stream = dist_plan.shared_comm_stream(getattr(ops, "device", torch.device("cuda", torch.cuda.current_device())))
             self._ev_a, self._ev_b = torch.cuda.Event(), torch.cuda.Event()
         # native replay of the cycle (dist_plan.py)
         plan_ok = (self.mode == "fused" and getattr(ops, "plan_capable", False) and self.Ld > 0 and
@@ -424,6 +459,40 @@ class DistributedMultigrid:
         self._norm_pending = False               # the back part's sum of r^2 is still on its way to the host
         self.speculate = True                    # queue the next cycle's front part before waiting for the norm
         self.native_cycles = 0
+        # per-phase times of the cycle (diagnostics, profile_phases / collect_phase_times)
+        self.phase_times = None
+        self._phase_events = []
+
+    # ---- per-phase times (diagnostics) -----------------------------------------------------------
+    def profile_phases(self, enable=True):
+        """Bracket the phases of the coming cycles -- fused legs, halo copies, send/recv groups (incl. the wait for the
+        peers), the coarse all-gather, the replicated engine, the norm all-reduce -- with timers: timing events on the stream a
+        phase runs on for device tensors (inside the C++ plan executor when cycles are replayed natively), wall clock for the
+        CPU stand-in.  For diagnostic cycles outside a timed region; collect_phase_times() returns milliseconds per phase."""
+        self.phase_times = {n: 0.0 for n in _lib.PLAN_PHASE_NAMES} if enable else None
+        self._phase_events = []
+        for pl in (self._plan, self._plan_back):
+            if pl is not None:
+                pl.profile(enable)
+
+    def collect_phase_times(self):
+        if self.phase_times is None:
+            return {}
+        if self._phase_events:
+            self.torch.cuda.synchronize()
+            for name, e0, e1 in self._phase_events:
+                self.phase_times[name] += e0.elapsed_time(e1)
+            self._phase_events = []
+        for pl in (self._plan, self._plan_back):
+            if pl is not None:
+                pl.phase_times(self.phase_times)
+        out = dict(self.phase_times)
+        for k in self.phase_times:
+            self.phase_times[k] = 0.0
+        return out
+
+    def _ph(self, name):
+        return _Phase(self, name)
 
     # ---- primitives the plan recorder sees ------------------------------------------------------
     def _copy(self, dst, src):
@@ -540,21 +609,25 @@ class DistributedMultigrid:
                             sends.append((p, sbuf))
                             recvs.append((p, rbuf))
                             unpack["corner"].append((dst, rbuf))
-        for dst, src in local["row"] + local["col"]:
-            self._copy(dst, src)
-        self._p2p(sends, recvs)
-        for dst, src in unpack["col"] + local["corner"] + unpack["corner"]:
-            self._copy(dst, src)
+        with self._ph("halo_copy"):
+            for dst, src in local["row"] + local["col"]:
+                self._copy(dst, src)
+        with self._ph("halo_exchange"):
+            self._p2p(sends, recvs)
+        with self._ph("halo_copy"):
+            for dst, src in unpack["col"] + local["corner"] + unpack["corner"]:
+                self._copy(dst, src)
 
     def allreduce_sum(self, parts):
         """parts: {rank: 1-element fp64 tensor}.  Returns the global sum as a Python float."""
         total = None
-        for r in self.ranks:
-            total = parts[r] if total is None else self._add(total, parts[r])
-        if self.dist is not None:
-            self.dist.all_reduce(total)
-            if self._rec is not None:
-                self._rec.allreduce(total)
+        with self._ph("allreduce"):
+            for r in self.ranks:
+                total = parts[r] if total is None else self._add(total, parts[r])
+            if self.dist is not None:
+                self.dist.all_reduce(total)
+                if self._rec is not None:
+                    self._rec.allreduce(total)
         if self._rec is not None:
             self._rec.result(total)
         return float(total.item())
@@ -587,17 +660,20 @@ class DistributedMultigrid:
     def _replicated_cycle(self, l):
         """Coarse tail: gather the coarse rhs, run the remaining levels on the single-GPU engine (on every GPU),
         take this rank's piece of the correction (ghost zone included: it is global data)."""
-        self._gather_coarse_rhs()
-        if self.mode == "fused" and getattr(self.ops, "plan_capable", False):
-            self.ops.coarse_begin(self.rhs_a, same_ring=True)      # the ring went in with set_problem
-        else:
-            self.ops.coarse_begin(self.rhs_a)
-        for _ in range(self._reps(l)):
-            self.ops.coarse_cycle()
-        self.ops.coarse_end(self.e_a)
-        for d in self.doms.values():
-            bc = d.blk[l + 1]
-            self._copy(d.ec[:bc.lnx, :bc.lny], self.e_a[bc.gx0:bc.gx0 + bc.lnx, bc.gy0:bc.gy0 + bc.lny])
+        with self._ph("coarse_allgather"):
+            self._gather_coarse_rhs()
+        with self._ph("replicated_engine"):
+            if self.mode == "fused" and getattr(self.ops, "plan_capable", False):
+                self.ops.coarse_begin(self.rhs_a, same_ring=True)      # the ring went in with set_problem
+            else:
+                self.ops.coarse_begin(self.rhs_a)
+            for _ in range(self._reps(l)):
+                self.ops.coarse_cycle()
+            self.ops.coarse_end(self.e_a)
+        with self._ph("halo_copy"):
+            for d in self.doms.values():
+                bc = d.blk[l + 1]
+                self._copy(d.ec[:bc.lnx, :bc.lny], self.e_a[bc.gx0:bc.gx0 + bc.lnx, bc.gy0:bc.gy0 + bc.lny])
 
     # ---- the cycle (solvers/multigrid.py:253-337) ------------------------------------------------
     def _reps(self, l):
@@ -631,6 +707,9 @@ class DistributedMultigrid:
         self._norm_value = None
         if self.native and l == 0 and not zero_u:
             return self._cycle_native()
+        # an eager cycle after native ones: collect a norm still in flight and forget a queued front part -- it was computed
+        # from the iterate this cycle is about to replace
+        self._settle()
         if self.mode == "fused":
             return self._cycle_fused(l, zero_u)
         return self._cycle_per_operator(l)
@@ -693,6 +772,9 @@ class DistributedMultigrid:
                 self._plan = dist_plan.CyclePlan(rec, self._comm, device.index or 0, 0, split)          # front part
                 self._plan_back = dist_plan.CyclePlan(rec, self._comm, device.index or 0, split, None)
                 self._plan_state = state
+                if self.phase_times is not None:
+                    self._plan.profile(True)
+                    self._plan_back.profile(True)
             except Exception as exc:
                 failure = exc
             if self.dist is not None:
@@ -746,9 +828,10 @@ class DistributedMultigrid:
                 ci, cj = b.coarse_offsets(bc)
                 target = d.rc if last else d.rhs[l + 1]
                 kw = {"acoef": d.a[l]} if self.var else {}
-                self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l], target, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, hx, hy,
-                                  self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1,
-                                  select, inner_of(b) if select else None, **kw)
+                with self._ph("legs"):
+                    self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l], target, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, hx, hy,
+                                      self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1,
+                                      select, inner_of(b) if select else None, **kw)
 
         def inner_rect(b):      # cells whose values do not come out of an exchange: owned cells and physical boundary
             big = 1 << 30
@@ -799,8 +882,9 @@ class DistributedMultigrid:
             e = d.ec if last else d.u[l + 1]
             win = (max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), max(b.j_lo, 1), min(b.j_hi, b.lny - 1)) if want_norm else None
             kw = {"acoef": d.a[l]} if self.var else {}
-            res = self.ops.up_leg(self.smk, d.u[l], d.rhs[l], d.t[l], e, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides, hx, hy,
-                                  self.omega, self.coeff, self.post, (b.gx0 + b.gy0) & 1, win, **kw)
+            with self._ph("legs"):
+                res = self.ops.up_leg(self.smk, d.u[l], d.rhs[l], d.t[l], e, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides, hx, hy,
+                                      self.omega, self.coeff, self.post, (b.gx0 + b.gy0) & 1, win, **kw)
             d.u[l], d.t[l] = d.t[l], d.u[l]
             if want_norm:
                 parts[r] = self._add(res, d.ring_sumsq)
@@ -1029,15 +1113,164 @@ class AdaptivePolicy:
         return guess < 10.0 * self.thr or stagnating(self.hist + [guess])
 
 
+class FixedPolicy:
+    """One working precision for the whole solve (the interface of AdaptivePolicy)."""
+
+    def __init__(self, name):
+        self.phase, self.promoted, self.hist, self.reason = name, True, [], None
+
+    def before_cycle(self, rn):
+        return self.phase
+
+    def after_cycle(self, rn):
+        self.hist.append(rn)
+
+    def switch_likely(self):
+        return False
+
+
+class DecomposedSolve:
+    """The loop of mg_iterate (csrc/mghip.hip; solvers/multigrid.py:219-246) on the decomposed hierarchy: policy check ->
+    cycle -> ||r|| -> record -> absolute stop test, driving one DistributedMultigrid per working precision (they share the
+    decomposition; the iterate moves between them with take_iterate_from, the on-device cast of
+    PrecisionManager.convert_array).  bench.py --gpus N and DistributedMultigridSolver.solve both run THIS loop.
+
+    solvers: {"f64": DistributedMultigrid, "f32": ...} (one entry for a fixed precision);
+    policy:  "fixed" or "adaptive" (AdaptivePolicy with `switch_threshold`)."""
+
+    def __init__(self, solvers, policy="fixed", switch_threshold=1e-6):
+        self.solvers = dict(solvers)
+        if policy not in ("fixed", "adaptive"):
+            raise ValueError(f"Unknown precision policy: {policy}")
+        if policy == "adaptive" and set(self.solvers) != {"f32", "f64"}:
+            raise ValueError("the adaptive policy switches between an 'f32' and an 'f64' solver")
+        self.policy_kind, self.thr = policy, switch_threshold
+        self.start = "f64" if "f64" in self.solvers else next(iter(self.solvers))
+        self.policy = None
+        self.rn = None
+        self.switches = 0
+
+    def _new_policy(self):
+        return AdaptivePolicy(self.thr) if self.policy_kind == "adaptive" else FixedPolicy(self.start)
+
+    def set_problem(self, rhs_of_block, u0_of_block=None):
+        """every precision takes the right-hand side (and the initial guess); a solve starts in `start` (double when there
+        is a choice: PrecisionManager's default precision, core/precision.py:26-45).  Returns the initial residual norm."""
+        for sv in self.solvers.values():
+            sv.set_problem(rhs_of_block, u0_of_block)
+        self.policy = self._new_policy()
+        self.switches = 0
+        self.rn = self.solvers[self.start].residual_norm()
+        return self.rn
+
+    @property
+    def current(self):
+        """the solver that holds the iterate"""
+        return self.solvers[self.policy.phase]
+
+    def step(self, tol=0.0):
+        """policy check (before the cycle, solvers/multigrid.py:224-227) -> cycle -> norm; returns the new norm"""
+        policy, solvers = self.policy, self.solvers
+        had = policy.phase
+        now = policy.before_cycle(self.rn)
+        if now != had:
+            solvers[now].take_iterate_from(solvers[had])
+            self.switches += 1
+        sv = solvers[now]
+        # no speculative front part across a precision switch the policy can see coming, nor across the end of the solve
+        # (it would run and be dropped): the norm in flight extrapolated from the last two, as iterate_impl does
+        ends = False
+        if tol > 0.0 and len(policy.hist) >= 2 and policy.hist[-2] > 0:
+            ends = policy.hist[-1] * min(1.0, policy.hist[-1] / policy.hist[-2]) < tol
+        sv.speculate = not (policy.switch_likely() or ends)
+        sv.cycle(0)
+        self.rn = sv.residual_norm()
+        policy.after_cycle(self.rn)
+        return self.rn
+
+    def run(self, tol, max_iterations):
+        """-> (history, phase per cycle, converged): cycles until ||r|| < tol (absolute, solvers/base.py:134)"""
+        hist, phases = [], []
+        converged = False
+        for _ in range(max_iterations):
+            rn = self.step(tol)
+            hist.append(rn)
+            phases.append(self.policy.phase)
+            if rn < tol:
+                converged = True
+                break
+        return hist, phases, converged
+
+    def close(self):
+        for sv in self.solvers.values():
+            sv.close()
+
+
+def _first_difference(a, b):
+    """(i, j) of the first element where two equally shaped tensors differ bitwise, or None"""
+    import torch
+    ne = (a.view(torch.int64 if a.element_size() == 8 else torch.int32) != b.view(torch.int64 if b.element_size() == 8 else torch.int32))
+    idx = torch.nonzero(ne)
+    return None if idx.numel() == 0 else tuple(int(v) for v in idx[0])
+
+
+def plan_selfcheck(sv, set_problem, dist):
+    """Before the clock: one cycle through the Python driver and the same cycle replayed from the recorded plan, from the
+    same start, must leave the same iterate BIT FOR BIT on every rank and the same norm.  Returns a dict for the bench line;
+    mismatch = {"rank", "first_diff", ...} on the ranks that differ (the caller aborts non-zero)."""
+    torch = sv.torch
+    if not sv.native:
+        return {"ran": False, "reason": "python driver only (no native plan on this backend / mode)"}
+    (r, d), = sv.doms.items()
+    b = d.blk[0]
+    was = sv.native
+    set_problem(sv)
+    sv.native = False
+    sv.cycle(0)
+    n_py = sv.residual_norm()
+    u_py = d.u[0][:b.lnx, :b.lny].clone()
+    sv.native = was
+    set_problem(sv)
+    sv.cycle(0)                       # records (first time) or replays
+    sv.residual_norm()
+    if sv.native:                     # the recording did not fall back: this one is a replay for certain
+        set_problem(sv)
+        replays_before = sv.native_cycles
+        sv.cycle(0)
+        n_na = sv.residual_norm()
+        replayed = sv.native_cycles == replays_before + 1
+        u_na = d.u[0][:b.lnx, :b.lny]
+        diff = _first_difference(u_py, u_na)
+        bad = (diff is not None) or not (n_py == n_na)
+    else:
+        replayed, diff, bad, n_na = False, None, False, n_py
+    flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device=u_py.device)
+    if dist is not None:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    res = {"ran": True, "replayed": bool(replayed), "bit_identical": not bool(int(flag.item())), "norm_python": n_py, "norm_native": n_na}
+    if bad:
+        res["mismatch"] = {"rank": r, "block": [b.gx0, b.gy0, b.lnx, b.lny], "first_diff": diff}
+    return res
+
+
 def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1): BASELINE config 3's workload per GPU (4097^2, adaptive fp32 -> fp64, V(2,2) weighted
     Jacobi) on a px x py block decomposition -- weak scaling of the N = 1 bench line.  The precision policy is the
     engine's (core/precision.py:270-302 with the one-way promotion): start in double, drop to single while
-    ||r|| > 100 thr, promote for good once ||r|| < 10 thr; it switches between two solvers that share the decomposition.
+    ||r|| > 100 thr, promote for good once ||r|| < 10 thr; it switches between two solvers that share the decomposition
+    (DecomposedSolve: the loop DistributedMultigridSolver.solve runs too).
+
+    Before the clock starts the run checks itself: every rank of the communicator is counted (`ranks_seen`), one cycle is
+    run through the Python driver and replayed from the recorded plan from the same start and the two iterates are compared
+    bit for bit (`selfcheck`; a mismatch prints the first differing block and exits non-zero).  After the timed region three
+    diagnostic cycles are bracketed with timing events per phase (`phases_ms_per_cycle`: legs, halo copies, send/recv groups
+    incl. the wait for the peers, coarse all-gather, replicated engine, all-reduce).  A rank whose plan times out
+    (MG_PLAN_TIMEOUT_S) reports and leaves with os._exit -- it never synchronises on the stuck streams again.
 
     Test hook (tests/test_distributed_cpu.py): MG_DIST_BACKEND=gloo with MG_BENCH_OPS=module:Class runs the same driver
     on CPU tensors with a stand-in kernel provider; without it the kernels are libmghip's and a GPU is required."""
     import importlib
+    import sys
     import torch
     import torch.distributed as dist
     if world != args.gpus:
@@ -1055,6 +1288,18 @@ def bench_main(args, rank, local_rank, world):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend)
+    try:
+        return _bench_ranks(args, rank, local_rank, world, backend, ops_spec, on_gpu, torch, dist, importlib)
+    except _lib.PlanTimeout as exc:
+        # the RCCL work of the stuck cycle is still queued: any synchronisation (torch.cuda.synchronize, mg_destroy, hipFree,
+        # destroy_process_group) would hang on it.  Report and leave; the launcher tears the other ranks down.
+        sys.stderr.write(f"bench.py rank {rank}: {exc}\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+
+def _bench_ranks(args, rank, local_rank, world, backend, ops_spec, on_gpu, torch, dist, importlib):
+    import sys
     px, py = process_grid(world)
     m = args.n - 1
     NX, NY = px * m + 1, py * m + 1
@@ -1076,47 +1321,57 @@ def bench_main(args, rank, local_rank, world):
         solvers[name] = DistributedMultigrid(NX, NY, px, py, [rank], ops, dist, domain=domain, smoother="jacobi", omega=0.8,
                                              cycle="V", pre=2, post=2, agglomerate_at=getattr(args, "agglomerate_at", 1025),
                                              native=native)
+    loop = DecomposedSolve(solvers, "adaptive", thr)
+    rhs_of = lambda b: sine_rhs_block(b, domain)
 
-    def reset():
-        for sv in solvers.values():
-            sv.set_problem(lambda b: sine_rhs_block(b, domain))
-        return AdaptivePolicy(thr), solvers["f64"].residual_norm()
+    # ---- who is here: every rank adds one, over torch.distributed and (native plans) over the library's own communicator ----
+    seen = torch.ones(1, dtype=torch.int32, device="cuda" if (on_gpu and backend == "nccl") else "cpu")
+    dist.all_reduce(seen)
+    ranks_seen = int(seen.item())
+    who = [None] * world
+    dist.all_gather_object(who, {"rank": rank, "device": (torch.cuda.current_device() if on_gpu else "cpu"), "pid": os.getpid()})
 
-    def step(policy, rn):
-        """policy check (before the cycle, solvers/multigrid.py:224-227) -> cycle -> norm"""
-        had = policy.phase
-        now = policy.before_cycle(rn)
-        if now != had:
-            solvers[now].take_iterate_from(solvers[had])
-        # no speculative front part across a precision switch the policy can see coming (it would run and be dropped)
-        solvers[now].speculate = not policy.switch_likely()
-        solvers[now].cycle(0)
-        rn = solvers[now].residual_norm()
-        policy.after_cycle(rn)
-        return rn
+    # ---- untimed set-up: the plan self-check builds both cycle plans (and the library's RCCL communicator) -------------------
+    checks = {}
+    for name, sv in solvers.items():
+        checks[name] = plan_selfcheck(sv, lambda s: s.set_problem(rhs_of), dist)
+    failed = [c for c in checks.values() if c.get("ran") and not c["bit_identical"]]
+    if failed:
+        for name, c in checks.items():
+            if "mismatch" in c:
+                sys.stderr.write(f"bench.py rank {rank}: native replay != Python driver ({name}): {json.dumps(c['mismatch'])}\n")
+        sys.stderr.flush()
+        sync()
+        dist.barrier()
+        for x in solvers.values():
+            x.close()
+        dist.destroy_process_group()
+        return 4
+    comm_ranks = None
+    for sv in solvers.values():
+        if sv._comm is not None:
+            comm_ranks = sv._comm.ranks()[0]
+    for sv in solvers.values():           # the Python-driver fallback needs its warm-up too
+        if not sv.native:
+            sv.set_problem(rhs_of)
+            sv.cycle(0)
+            sv.residual_norm()
 
     K, W = args.steps, args.warmup
-    # untimed set-up: one cycle of EACH solver, so that both cycle plans (and the library's RCCL communicator) exist before
-    # the clock starts -- the adaptive policy reaches the fp64 solver only after the warm-up steps
-    reset()
-    for sv in solvers.values():
-        sv.cycle(0)
-        sv.residual_norm()
-    policy, rn = reset()
+    loop.set_problem(rhs_of)
     for _ in range(W):
-        rn = step(policy, rn)
-    policy, rn = reset()
-    r0 = rn
+        loop.step()
+    r0 = loop.set_problem(rhs_of)
     hist, phases = [], []
     for sv in solvers.values():
         sv.exchanges = 0
+        sv.native_cycles = 0
     dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(K):
-        rn = step(policy, rn)
-        hist.append(rn)
-        phases.append(policy.phase)
+        hist.append(loop.step())
+        phases.append(loop.policy.phase)
     sync()
     dist.barrier()
     dt = time.perf_counter() - t0
@@ -1124,18 +1379,28 @@ def bench_main(args, rank, local_rank, world):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     exchanges = sum(x.exchanges for x in solvers.values()) / max(1, K)
+    native_cycles = sum(x.native_cycles for x in solvers.values())
     # iterations to tolerance / the plateau of the reference's absolute norm (untimed continuation of the same solve)
     long_hist = list(hist)
     for _ in range(max(0, 40 - K)):
-        rn = step(policy, rn)
-        long_hist.append(rn)
+        long_hist.append(loop.step())
     tail = sorted(long_hist[-5:])
     floor = tail[len(tail) // 2]
     first = lambda vals, t: next((k + 1 for k, v in enumerate(vals) if v < t), None)
-    # roofline leg (rank 0): the dominant kernel of the timed region -- the level-0 up leg (prolongation + 2 sweeps +
-    # norm) of the precision that ran most cycles -- on this rank's block, timed with events on its own stream
+    # ---- per-phase device times: three more cycles of the dominant precision, every phase bracketed by timing events ------
     dom = "f64" if phases.count("f64") >= phases.count("f32") else "f32"
     sv = solvers[dom]
+    sv.profile_phases(True)
+    ncyc = 3
+    for _ in range(ncyc):
+        sv.cycle(0)
+        sv.residual_norm()
+    ph = sv.collect_phase_times()
+    sv.profile_phases(False)
+    phases_ms = {k: v / ncyc for k, v in ph.items()}
+    # roofline leg (rank 0): the dominant kernel of the timed region -- the level-0 up leg (prolongation + 2 sweeps +
+    # norm) of the precision that ran most cycles -- on this rank's block, timed with events on its own stream
+    sv._settle()
     d0 = sv.doms[rank]
     b0, b1 = d0.blk[0], d0.blk[1]
     hx0, hy0 = sv.h[0]
@@ -1189,15 +1454,23 @@ def bench_main(args, rank, local_rank, world):
                                  "included) / launch time; unfused_equivalent_* prices the same work as one launch per operator "
                                  "(SURVEY 8d)"},
             "exchanges_per_cycle": exchanges,
-            "driver": {"native_plan_cycles": sum(x.native_cycles for x in solvers.values()),
-                       "python_cycles": 2 + W + len(long_hist) - sum(x.native_cycles for x in solvers.values()),
-                       "fallback": next((x.native_failure for x in solvers.values() if x.native_failure), None)},
+            "ranks_seen": ranks_seen, "rank_devices": who,
+            "driver": {"native_plan_cycles": native_cycles, "python_cycles": K - native_cycles,
+                       "fallback": next((x.native_failure for x in solvers.values() if x.native_failure), None),
+                       "rccl_comm_ranks": comm_ranks,
+                       "rccl_multi_rank_replay": ("exercised in this run" if (native_cycles > 0 and world > 1 and backend == "nccl") else
+                                                  "not exercised (no multi-rank RCCL plan ran here)"),
+                       "selfcheck": checks},
+            "phases_ms_per_cycle": dict(phases_ms, precision=dom, cycles=ncyc, rank=0,
+                                        source=("timing events inside mg_plan_run" if sv.native else
+                                                ("timing events around the Python driver's phases" if on_gpu else "wall clock (CPU rehearsal)"))),
             "note": "distributed levels: communication-avoiding fused legs (two launches and about one halo exchange per "
                     "level and cycle); a cycle is recorded once through the Python driver and then replayed from C++ -- one "
                     "mg_plan_run per cycle enqueues the kernels, the RCCL send/recv groups, the coarse all-gather and the "
                     "norm all-reduce on two HIP streams (MG_DIST_NATIVE=0: torch.distributed P2P from Python every cycle); "
                     "the replicated coarse hierarchy runs on the fused single-GPU engine; same precision policy as the "
-                    "N = 1 line",
+                    "N = 1 line; multi-rank RCCL replay has never run before the first real multi-GPU run: `driver` says which "
+                    "path this run took and `selfcheck` that replay and Python driver agreed bit for bit before the clock",
         }), flush=True)
     for x in solvers.values():
         x.close()

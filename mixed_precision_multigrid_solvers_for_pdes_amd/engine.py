@@ -13,8 +13,13 @@ class MultigridEngine:
                  smoother=_lib.MG_JACOBI, omega=0.8, coarse_tol=1e-12, coarse_maxit=1000,
                  precision=_lib.MG_PREC_DOUBLE, switch_threshold=1e-6, memory_threshold_gb=4.0,
                  adaptive_reference_rule=False, device=0, profile=False, colour_offset=0, fused=2, tail=True, speculate=True, fmg_cycles=0,
-                 mixed_split=0, coarse_direct=False):
+                 mixed_split=0, coarse_direct=None):
         lib = _lib.load()
+        # coarse_direct: True the nine unknowns of a 5 x 5 coarsest grid are solved directly (u = A^-1 f; within 1e-12 of the
+        # reference's iterates, not bit-identical), False by the reference's Gauss-Seidel iteration to coarse_tol (bit-identical),
+        # None (default) directly in W- / F-cycles -- 2^(L-1) coarsest visits per cycle -- and by the iteration in V-cycles.
+        # tail: True / 1 the coarse levels run in the register-resident one-workgroup kernel where it applies (dyadic square
+        # levels <= 65^2, csrc/mg_tail_kernels.hpp) and in the LDS one elsewhere; 2 the LDS kernel only; False / 0 one launch pair per level.
         # fused: 0 / False one launch per operator; 1 / True fused legs tiled through LDS; 2 (default) the same legs
         # register-blocked on levels above ~1100^2 cells; 3 register-blocked on every level (include/mghip.h mg_config.fused)
         if isinstance(cycle, str):
@@ -25,8 +30,8 @@ class MultigridEngine:
                             float(coeff), int(max_levels), int(cycle), int(pre), int(post), int(smoother),
                             float(omega), float(coarse_tol), int(coarse_maxit), int(precision),
                             float(switch_threshold), float(memory_threshold_gb), int(bool(adaptive_reference_rule)),
-                            int(device), int(bool(profile)), int(colour_offset), int(fused), int(bool(tail)), int(fmg_cycles), int(bool(speculate)),
-                            int(bool(coarse_direct)), int(mixed_split))
+                            int(device), int(bool(profile)), int(colour_offset), int(fused), int(tail), int(fmg_cycles), int(bool(speculate)),
+                            -1 if coarse_direct is None else int(bool(coarse_direct)), int(mixed_split))
         self.cfg = cfg
         self._h = C.c_void_p(None)
         _lib.check(lib.mg_create(C.byref(cfg), C.byref(self._h)))

@@ -110,7 +110,11 @@ class MixedPrecisionMultigrid:
     def __init__(self, precision_strategy="adaptive", switch_threshold=1e-6, use_gpu=True, max_levels=None,
                  max_iterations=50, tolerance=1e-8, cycle_type="V", pre_smooth_iterations=2,
                  post_smooth_iterations=2, smoother="jacobi", relaxation_parameter=None, device_id=0,
-                 coarse_tolerance=1e-12, coarse_max_iterations=1000, use_fmg=False, fmg_cycles=1):
+                 coarse_tolerance=1e-12, coarse_max_iterations=1000, use_fmg=False, fmg_cycles=1, n_gpus=1, device_ids=None,
+                 decomposition_strategy="block", agglomerate_at=1025):
+        """n_gpus > 1 (or device_ids with more than one entry, or a torch.distributed job of more than one rank): the solve
+        runs block domain-decomposed through DistributedMultigridSolver (multi_gpu.py) -- one process per GPU under
+        torch.distributed, virtual ranks on one GPU otherwise -- and returns the single-GPU solve's iterate."""
         if precision_strategy not in self.STRATEGIES:
             raise ValueError(f"Unknown precision strategy: {precision_strategy}")
         if smoother not in ("jacobi", "gauss_seidel", "red_black", "sor"):
@@ -127,6 +131,9 @@ class MixedPrecisionMultigrid:
         self.device_id = device_id
         self.coarse_tolerance, self.coarse_max_iterations = coarse_tolerance, coarse_max_iterations
         self.use_fmg, self.fmg_cycles = use_fmg, fmg_cycles
+        self.device_ids = list(device_ids) if device_ids is not None else ([device_id] * int(n_gpus) if int(n_gpus) > 1 else None)
+        self.n_gpus = len(self.device_ids) if self.device_ids else 1
+        self.decomposition_strategy, self.agglomerate_at = decomposition_strategy, agglomerate_at
         if use_gpu:
             _lib.load()                                 # fail at construction, not at first solve
             if _lib.device_count() <= device_id:
@@ -165,7 +172,27 @@ class MixedPrecisionMultigrid:
         rhs = problem.rhs(dtype)
         u0 = initial_guess if initial_guess is not None else problem.initial_guess(dtype)
         t0 = time.time()
-        if self.use_gpu:
+        from .multi_gpu import DistributedMultigridSolver, _dist_if_initialised
+        if self.use_gpu and (self.n_gpus > 1 or _dist_if_initialised() is not None):
+            if self.precision_strategy in ("adaptive_reference", "defect") or self.use_fmg:
+                raise NotImplementedError("the decomposed solver runs the 'double', 'single', 'mixed' and 'adaptive' strategies "
+                                          "without a full-multigrid start")
+            grid = problem.grid(dtype)
+            name = {"jacobi": "jacobi", "gauss_seidel": "gauss_seidel", "red_black": "gauss_seidel", "sor": "sor"}[self.smoother]
+            solver = DistributedMultigridSolver(device_ids=self.device_ids, decomposition_strategy=self.decomposition_strategy,
+                                                agglomerate_at=self.agglomerate_at, max_levels=levels,
+                                                max_iterations=self.max_iterations, tolerance=self.tolerance,
+                                                cycle_type=self.cycle_type, pre_smooth_iterations=self.pre,
+                                                post_smooth_iterations=self.post, smoother=name, relaxation_parameter=self.omega,
+                                                coarse_tolerance=self.coarse_tolerance,
+                                                coarse_max_iterations=self.coarse_max_iterations)
+            op = LaplacianOperator(coefficient=-1.0)
+            solver.setup(grid, op, RestrictionOperator("full_weighting"), ProlongationOperator("bilinear"))
+            try:
+                u, info = solver.solve(grid, op, rhs, u0, self._precision_manager())
+            finally:
+                solver.cleanup()
+        elif self.use_gpu:
             grid = problem.grid(dtype)
             solver = MultigridSolver(levels, self.max_iterations, self.tolerance, self.cycle_type, self.pre, self.post,
                                      self.coarse_tolerance, self.coarse_max_iterations, device_id=self.device_id,

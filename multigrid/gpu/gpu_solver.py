@@ -1,2 +1,2 @@
 """multigrid.gpu.gpu_solver (reference: src/multigrid/gpu/gpu_solver.py)."""
-from mixed_precision_multigrid_solvers_for_pdes_amd.solver import GPUMultigridSolver   # noqa: F401
+from mixed_precision_multigrid_solvers_for_pdes_amd.solver import GPUCommunicationAvoidingMultigrid, GPUMultigridSolver   # noqa: F401

@@ -19,8 +19,14 @@ PATHS = [
     ("multigrid.solvers.smoothers", ["JacobiSmoother", "WeightedJacobiSmoother", "GaussSeidelSmoother"]),
     ("multigrid.solvers.iterative", ["EnhancedJacobiSolver"]),
     ("multigrid.solvers.base", ["BaseSolver", "IterativeSolver"]),
-    ("multigrid.gpu", ["GPUMultigridSolver"]),
-    ("multigrid.gpu.gpu_solver", ["GPUMultigridSolver"]),
+    ("multigrid.gpu", ["GPUMemoryManager", "GPUMemoryPool", "CUDAKernels", "SmoothingKernels", "TransferKernels", "GPUMultigridSolver",
+                       "GPUCommunicationAvoidingMultigrid", "GPUPrecisionManager"]),          # gpu/__init__.py:3-6
+    ("multigrid.gpu.gpu_solver", ["GPUMultigridSolver", "GPUCommunicationAvoidingMultigrid"]),
+    ("multigrid.gpu.gpu_precision", ["GPUPrecisionManager", "GPUPrecisionLevel"]),
+    ("multigrid.gpu.memory_manager", ["GPUMemoryManager", "GPUMemoryPool", "check_gpu_availability"]),
+    ("multigrid.gpu.multi_gpu", ["DistributedMultigridSolver", "MultiGPUManager"]),
+    ("multigrid.gpu.multi_gpu_solver", ["MultiGPUSolver", "DecompositionType"]),
+    ("multigrid.gpu.cuda_kernels", ["CUDAKernels", "SmoothingKernels", "TransferKernels", "MixedPrecisionKernels"]),
     ("multigrid.problems", ["PoissonProblem"]),
     ("multigrid.applications", ["PoissonSolver2D", "PoissonProblem", "HeatEquationSolver"]),
     ("multigrid.applications.poisson_solver", ["PoissonSolver2D", "PoissonProblem"]),
@@ -44,3 +50,19 @@ def test_readme_facade_names():
     from multigrid.solvers import MixedPrecisionMultigrid
     from multigrid.problems import PoissonProblem
     assert MixedPrecisionMultigrid is mg.MixedPrecisionMultigrid and PoissonProblem is mg.PoissonProblem
+
+
+def test_the_reference_callers_import_lines_bind_to_the_hip_path():
+    """applications/poisson_solver.py:15-19 of the reference guards exactly this line with `except ImportError` and then runs
+    its CPU path SILENTLY; gpu/__init__.py:3-6 are the package's own imports.  Executed verbatim against this repo's
+    `multigrid` namespace they must resolve -- to the MI355X classes."""
+    ns = {}
+    exec("from multigrid.gpu.gpu_solver import GPUMultigridSolver, GPUCommunicationAvoidingMultigrid", ns)
+    exec("from multigrid.gpu import GPUMemoryManager, GPUMemoryPool, CUDAKernels, SmoothingKernels, TransferKernels", ns)
+    exec("from multigrid.gpu import GPUPrecisionManager", ns)
+    exec("from multigrid.gpu.multi_gpu import DistributedMultigridSolver", ns)
+    assert ns["GPUCommunicationAvoidingMultigrid"] is mg.GPUCommunicationAvoidingMultigrid
+    assert issubclass(ns["GPUCommunicationAvoidingMultigrid"], ns["GPUMultigridSolver"])
+    assert ns["DistributedMultigridSolver"] is mg.DistributedMultigridSolver
+    import multigrid
+    assert multigrid.GPU_AVAILABLE is True

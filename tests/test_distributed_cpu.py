@@ -338,6 +338,16 @@ def test_bench_py_gpus_2_launches_its_own_ranks():
     assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["unit"] == "GB/s"
     # the solve itself: starts in double, drops to single on the large first residual (AdaptivePolicy), contracts
     assert d["cycles_fp32"] >= 1 and d["residual_first"] < 0.2 * d["residual_initial"]
+    # the run diagnoses itself: who took part, which driver ran the cycles, where a cycle's time went
+    assert d["ranks_seen"] == 2 and sorted(w["rank"] for w in d["rank_devices"]) == [0, 1]
+    drv = d["driver"]
+    assert drv["native_plan_cycles"] == 0 and drv["python_cycles"] == 3 and drv["fallback"] is None      # gloo: no RCCL plans
+    assert drv["rccl_multi_rank_replay"].startswith("not exercised")
+    assert all(c["ran"] is False for c in drv["selfcheck"].values())               # nothing to replay on this backend
+    ph = d["phases_ms_per_cycle"]
+    for k in ("legs", "halo_copy", "halo_exchange", "coarse_allgather", "replicated_engine", "allreduce"):
+        assert k in ph and ph[k] >= 0.0, k
+    assert ph["legs"] > 0.0 and ph["halo_exchange"] > 0.0 and ph["replicated_engine"] > 0.0 and ph["cycles"] == 3
     # a rank that fails must fail the launcher
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                           "--grid-n", "64", "--agglomerate-at", "17"], env=env, capture_output=True, text=True, timeout=600)

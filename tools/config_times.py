@@ -33,7 +33,7 @@ for name, n, cyc, sm, omega, prec, its, var in cases:
     x = np.linspace(0, 1, n)
     rhs = 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
     eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), cycle=cyc, smoother=sm, omega=omega, precision=prec,
-                             coarse_direct=os.environ.get("MG_COARSE_DIRECT") == "1")     # 1: exact 5 x 5 coarsest solve (not the reference's iteration)
+                             coarse_direct={"1": True, "0": False}.get(os.environ.get("MG_COARSE_DIRECT")))     # 1: exact 5 x 5 coarsest solve (not the reference's iteration)
     if var:
         eng.set_coefficient(1.0 + 0.5 * np.sin(2 * np.pi * x)[:, None] * np.cos(2 * np.pi * x)[None, :])
     eng.set_rhs(rhs)
