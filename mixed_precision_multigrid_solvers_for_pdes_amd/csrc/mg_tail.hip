@@ -20,10 +20,10 @@ bool dyadic_square_tail(const mg_handle* h, int k) {
   return true;
 }
 
-template <typename T, typename TCO, typename TC, int SM, int NCTOP>
-int launch_t(mg_handle* h, const mg::Tail2Args& a, const void* rhs, void* u, bool zero_top) {
+template <typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV>
+int launch_d(mg_handle* h, const mg::Tail2Args& a, const void* rhs, void* u, bool zero_top) {
   using L = mg::T2Lds<T, TCO, NCTOP>;
-  auto k = mg::tail2_kernel<T, TCO, TC, SM, NCTOP>;
+  auto k = mg::tail2_kernel<T, TCO, TC, SM, NCTOP, DIV>;
   static bool attr_done = false;                       // per instantiation
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::kTotal) != hipSuccess)
@@ -33,6 +33,15 @@ int launch_t(mg_handle* h, const mg::Tail2Args& a, const void* rhs, void* u, boo
   hipLaunchKernelGGL(k, dim3(1), dim3(mg::T2Geo<NCTOP>::WAVES * 64), L::kTotal, h->stream, (const T*)rhs, (T*)u, a, zero_top ? 1 : 0,
                      h->d_int);
   return MG_OK;
+}
+
+// DIV: some level's diagonal has no exact reciprocal (a Helmholtz shift): divide, as the reference does; otherwise every
+// level multiplies by the exact 1 / D (bit-identical to the division)
+template <typename T, typename TCO, typename TC, int SM, int NCTOP>
+int launch_t(mg_handle* h, const mg::Tail2Args& a, const void* rhs, void* u, bool zero_top) {
+  bool div = false;
+  for (int l = h->tail2_start; l <= h->L() - 2; ++l) div = div || !coefs(h->lv[l].hx, h->lv[l].hy, h->sigma).pow2;
+  return div ? launch_d<T, TCO, TC, SM, NCTOP, true>(h, a, rhs, u, zero_top) : launch_d<T, TCO, TC, SM, NCTOP, false>(h, a, rhs, u, zero_top);
 }
 
 template <typename T, typename TCO, typename TC, int SM>
@@ -97,7 +106,7 @@ int tail2_launch(mg_handle* h, bool zero_top) {
     const Level& v = h->lv[l];
     const Coef c = coefs(v.hx, v.hy, h->sigma);
     mg::Tail2Level& t = a.lv[l - k];
-    t.ihx2 = c.ihx2; t.ihy2 = c.ihy2; t.invD = c.invD; t.diag = c.diag; t.use_div = c.pow2 ? 0 : 1;
+    t.ihx2 = c.ihx2; t.ihy2 = c.ihy2; t.invD = c.invD; t.diag = c.diag;
     int reps = 1;
     if (h->cfg.cycle == MG_CYCLE_W) reps = 2;
     else if (h->cfg.cycle == MG_CYCLE_F) reps = std::max(1, 1 << std::max(0, L - l - 2));
@@ -117,3 +126,10 @@ int tail2_launch(mg_handle* h, bool zero_top) {
 }
 
 }  // namespace mgh
+
+#if MG_EXP_TAIL_TRACE
+// timing experiment: the (id, ticks) stamps of the last tail2_kernel launch (mg_tail_kernels.hpp)
+extern "C" int mg_exp_tail2_trace(long long* out, int cap) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mg::g_tail2_trace), sizeof(long long) * (size_t)cap) == hipSuccess ? MG_OK : MG_ERR_HIP;
+}
+#endif
