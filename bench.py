@@ -263,19 +263,25 @@ def main():
     dom_p = "f64" if t64 >= t32 else "f32"
     dom_k = "up_leg" if kern[dom_p]["up_leg"]["launch_ms"] >= kern[dom_p]["down_leg"]["launch_ms"] else "down_leg"
     dom = kern[dom_p][dom_k]
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_build = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    from mixed_precision_multigrid_solvers_for_pdes_amd import _build
+    build_now = _build.source_hash()
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path))["kernels"][f"{dom_k}_{dom_p}_{n}"]["hbm_bytes_per_launch_corrected"]
+            pmc = json.load(open(pmc_path))
+            traffic = pmc["kernels"][f"{dom_k}_{dom_p}_{n}"]["hbm_bytes_per_launch_corrected"]
+            traffic_build = pmc.get("source_hash")
             traffic_source = ("profiles/pmc_latest.json: stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel "
-                              "(FETCH doubled per the gfx950 note); not measured in this run")
+                              "(FETCH doubled per the gfx950 note); not measured in this run -- traffic_build is the source hash "
+                              "of the library those passes ran, build the one of this run")
         except Exception:
             traffic = None
     roof = {"bound": "hbm",
             "kernel": f"rb_leg_kernel {dom_k} {dom_p} at {n}^2 (level 0, register-blocked fused leg): the largest time share of the timed region",
             "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
-            "traffic_source": traffic_source,
+            "traffic_source": traffic_source, "traffic_build": traffic_build, "build": build_now,
+            "traffic_is_from_this_build": bool(traffic_build) and traffic_build == build_now,
             "launch_ms": dom["launch_ms"], "bytes_per_launch": dom["bytes_per_launch"],
             "frac_of_achievable": dom["frac_of_achievable"], "achievable_gbs": HBM_ACHIEVABLE_GBS,
             "unfused_equivalent_bytes": dom["unfused_equivalent_bytes"], "unfused_equivalent_gbs": dom["unfused_equivalent_gbs"],
@@ -293,6 +299,52 @@ def main():
                     "exceed the HBM peak",
             "kernels": kern}
 
+    # ---- time to solution: cycles and device time to the plateau of the absolute norm, per policy ----
+    def to_floor(engine):
+        engine.set_solution(None)
+        h40 = engine.iterate(tol=0.0, max_iterations=40)["residual_history"]
+        fl, its = floor_of(h40)
+        engine.set_solution(None)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rr = engine.iterate(tol=0.0, max_iterations=its)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        return {"iterations_to_floor": its, "time_to_floor_ms": el * 1e3, "residual_floor": fl, "ms_per_cycle": el / its * 1e3,
+                "cycles_fp32": sum(1 for c in rr["precision_codes"] if c == 0), "switch_reason": rr.get("switch_reason"),
+                "fp32_floor_estimate": rr.get("fp32_floor")}
+    tts = {"adaptive": to_floor(eng)}
+    for name, prec in (("double", _lib.MG_PREC_DOUBLE), ("defect", _lib.MG_PREC_DEFECT)):
+        e2 = mg.MultigridEngine(n, n, max_levels=levels, cycle="V", pre=2, post=2, smoother=_lib.MG_JACOBI, omega=0.8, precision=prec,
+                                device=local_rank)
+        e2.set_rhs(sine_rhs(n, n))
+        e2.iterate(tol=0.0, max_iterations=2)            # warm-up
+        tts[name] = to_floor(e2)
+        e2.close()
+    tts["note"] = ("floor = the plateau of the reference's absolute h-scaled norm (SURVEY F10); time = device-resident mg_iterate to "
+                   "the first cycle within 2x of it.  adaptive: one fp32 cycle, then promoted as soon as ||r|| is within 2x of the "
+                   "fp32 residual floor eps32 * diag(A) * ||u|| (switch_reason); defect: fp32 cycles on the error equation of an "
+                   "fp64 iterate")
+    # ---- the smoother against the stream ceiling by size: does the ceiling climb with launch length? ----
+    sweep = []
+    for m in (4097, 8193, 16385):
+        try:
+            if m == n:
+                e3 = None
+                a, b = kern["f32"]["jacobi_sweep_hbm"], kern["f32"]["stream_hbm"]
+                ms_j, ms_s = a["launch_ms"], b["launch_ms"]
+            else:
+                e3 = mg.MultigridEngine(m, m, max_levels=3, cycle="V", smoother=_lib.MG_JACOBI, omega=0.8, precision=_lib.MG_PREC_SINGLE,
+                                        device=local_rank)
+                e3.set_rhs(sine_rhs(m, m, np.float32))
+                ms_j, ms_s = e3.time_op("jacobi_hbm", 0, np.float32, 10), e3.time_op("stream_hbm", 0, np.float32, 10)
+                e3.close()
+            byts = 3.0 * 4 * m * m
+            sweep.append({"n": m, "dtype": "f32", "jacobi_sweep_hbm_ms": ms_j, "jacobi_sweep_hbm_gbs": byts / (ms_j * 1e-3) / 1e9,
+                          "jacobi_frac_of_8TBs": byts / (ms_j * 1e-3) / 1e9 / HBM_PEAK_GBS, "stream_hbm_ms": ms_s,
+                          "stream_hbm_gbs": byts / (ms_s * 1e-3) / 1e9, "stream_frac_of_8TBs": byts / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        except Exception as exc:                          # a box without the memory for the 16385^2 rotating sets
+            sweep.append({"n": m, "error": repr(exc)})
     out = {
         "metric": "MDoF/s per V-cycle on 2D Poisson", "value": value, "unit": "MDoF/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -304,7 +356,13 @@ def main():
         "residual_initial": r0, "residual_first": hist[0], "residual_last": hist[-1],
         "iterations": K,
         "iterations_to_1e-10_absolute": its_abs10, "iterations_to_1e-10_relative": its_rel, "iterations_to_1e-9_absolute": its_abs9,
-        "residual_floor": floor, "iterations_to_floor": its_floor,
+        "residual_floor": floor, "iterations_to_floor": its_floor, "time_to_floor_ms": tts["adaptive"]["time_to_floor_ms"],
+        "switch_reason": tts["adaptive"]["switch_reason"], "time_to_solution": tts,
+        "smoother_size_sweep": {"rows": sweep,
+                                "note": "single Jacobi sweep and the stencil-free c = a + b stream, fp32, operands rotating through "
+                                        "> 768 MiB (HBM proper), by grid size: if the fractions climb with n the 4097^2 figures are "
+                                        "launch-length-limited (a 25-40 us launch spends a visible share ramping up and draining); "
+                                        "if they do not, ~0.6 of 8 TB/s is what 2 reads + 1 write get from this memory system"},
         "reference_cpu_captured": reference_cpu_captured(),
         "roofline": roof,
     }

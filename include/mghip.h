@@ -75,7 +75,9 @@ typedef struct mg_config {
   double switch_threshold;   /* PrecisionManager.convergence_threshold                          */
   double memory_threshold_gb;/* PrecisionManager.memory_threshold_gb                            */
   int32_t adaptive_reference_rule; /* 1: the reference's two-way rule verbatim (never recovers);
-                                      0: one-way fp32 -> fp64 at ||r|| < 10*thr or on fp32 stagnation    */
+                                      0: one-way fp32 -> fp64 at ||r|| < 10*thr, on fp32 stagnation, or as soon as ||r|| is
+                                      within 2 x of the fp32 residual floor eps32 * diag(A) * ||u||_h (evaluated once, after
+                                      the first fp32 cycle: more fp32 cycles cannot lower the residual any further) */
   int32_t device;            /* HIP device ordinal                                              */
   int32_t profile;           /* 1: per-level stage timings (synchronising; solvers/multigrid.py:179-182) */
   int32_t colour_offset;     /* parity of the global index of local cell (0,0) (sub-domains)     */
@@ -112,6 +114,12 @@ typedef struct mg_stats {
   double initial_residual;   /* ||f - A u0||                                  (gpu/gpu_solver.py:243-251) */
   int32_t precision_switches;
   int32_t last_coarse_sweeps;
+  int32_t switch_reason;     /* MG_PREC_ADAPTIVE: why the fp32 phase ended -- 0 it did not (or never began), 1 ||r|| < 10 x
+                                switch_threshold (core/precision.py:248-268), 2 stagnation (core/precision.py:189-246),
+                                3 ||r|| within 2 x of the fp32 residual floor eps32 * diag(A) * ||u|| (ours), 4 the fp32 phase
+                                was never entered: that floor, bounded a priori by eps32 diag(A) / lambda_min ||r_0||, leaves it
+                                fewer than two useful cycles (ours; the solve is then a double solve) */
+  double fp32_floor;         /* that floor estimate (0: not evaluated) */
 } mg_stats;
 
 typedef struct mg_handle mg_handle;
@@ -269,16 +277,20 @@ int mg_dev_up_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, 
                   const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
                   int nj_hi, void* scratch, double* sumsq_dev, void* stream);
 /* The same legs for the variable-coefficient operator A = coeff * div(a grad .): `acoef` holds the vertex values of a on
- * this array (dtype / pitch of u, ghost zone included; NULL = the constant-coefficient legs above).  No reference
- * counterpart; see mg_set_coefficient. */
+ * this array (dtype / pitch of u, ghost zone included; NULL = the constant-coefficient legs above) and `rdiag` its
+ * reciprocal diagonal per cell, computed once per coefficient by mg_dev_var_rdiag (same dtype / pitch; NULL with acoef NULL):
+ * the sweeps multiply by it, no division per cell and sweep.  No reference counterpart; see mg_set_coefficient. */
 int mg_dev_down_leg_var(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
                         int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
                         const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream, int select, const int* inner_rect,
-                        const void* acoef);
+                        const void* acoef, const void* rdiag);
 int mg_dev_up_leg_var(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
                       int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
                       const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
-                      int nj_hi, void* scratch, double* sumsq_dev, void* stream, const void* acoef);
+                      int nj_hi, void* scratch, double* sumsq_dev, void* stream, const void* acoef, const void* rdiag);
+/* rdiag[i][j] = 1 / ((a(i+1/2) + a(i-1/2)) / hx^2 + (a(j+1/2) + a(j-1/2)) / hy^2 [+ sigma]) on interior cells (face values =
+ * arithmetic means of the vertex values), 0 on the ring of the array; rounded once in `dtype` */
+int mg_dev_var_rdiag(int dtype, int nx, int ny, int ld, double hx, double hy, double sigma, const void* a, void* rdiag, void* stream);
 /* boundary ring of a coarse field := injected fine values, on the physical edges (`sides`) only */
 int mg_dev_inject_ring(int in_dtype, int out_dtype, int nxf, int nyf, int ldf, int nxc, int nyc, int ldc, int sides, int ci_off,
                        int cj_off, const void* fine, void* coarse, void* stream);
@@ -298,10 +310,10 @@ int mg_pitch_elems(int dtype, int ny, int* ld);
 enum {
   MG_PLAN_DOWN_LEG = 1,    /* i: smoother, dtype, coarse_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off, cj_off, nsweep, zero_init,
                                  colour_offset, select, has_rect, rect[4];  d: hx, hy, omega, coeff;
-                                 p: u, rhs, out, rhs_coarse, acoef                                   (mg_dev_down_leg_var) */
+                                 p: u, rhs, out, rhs_coarse, acoef, rdiag                            (mg_dev_down_leg_var) */
   MG_PLAN_UP_LEG = 2,      /* i: smoother, dtype, coarse_dtype, compute_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off, cj_off, sides,
                                  nsweep, colour_offset, norm, window[4];  d: hx, hy, omega, coeff;
-                                 p: u, rhs, out, e_coarse, scratch, sumsq_dev, acoef                 (mg_dev_up_leg_var) */
+                                 p: u, rhs, out, e_coarse, scratch, sumsq_dev, acoef, rdiag          (mg_dev_up_leg_var) */
   MG_PLAN_COPY2D = 3,      /* i: rows, width_bytes, dst_pitch_bytes, src_pitch_bytes;  p: dst, src   (4-byte granularity) */
   MG_PLAN_ADD_F64 = 4,     /* p: dst, a, b:  *dst = *a + *b   (device doubles; b NULL: *dst = *a) */
   MG_PLAN_GROUP_BEGIN = 5, /* ncclGroupStart */

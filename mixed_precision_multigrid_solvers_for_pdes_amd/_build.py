@@ -16,6 +16,9 @@ SOURCES = [os.path.join(CSRC, n) for n in ("mghip.hip", "mg_plan.hip", "mg_tail.
 HEADERS = [os.path.join(CSRC, n) for n in ("mg_kernels.hpp", "mg_rb_kernels.hpp", "mg_tail_kernels.hpp", "mg_host.hpp")] + \
           [os.path.join(os.path.dirname(HERE), "include", "mghip.h")]
 DEPS = SOURCES + HEADERS
+# headers a unit does NOT include (directly or through another header): editing them leaves its object current
+NOT_INCLUDED = {"mghip.hip": ("mg_tail_kernels.hpp",),
+                "mg_plan.hip": ("mg_kernels.hpp", "mg_rb_kernels.hpp", "mg_tail_kernels.hpp", "mg_host.hpp")}
 # -ffp-contract=off: the kernels reproduce the reference's rounding sequence (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -33,6 +36,17 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def source_hash():
+    """sha1 over the kernel sources (csrc/*.hip, *.hpp and the C header): which build a stored measurement belongs to"""
+    import hashlib
+    h = hashlib.sha1()
+    for path in sorted(DEPS):
+        if os.path.exists(path):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def is_stale():
     if not os.path.exists(LIBPATH):
         return True
@@ -48,7 +62,9 @@ def _obj_stale(src, obj):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    return any(os.path.getmtime(d) > t for d in [src] + HEADERS if os.path.exists(d))
+    skip = NOT_INCLUDED.get(os.path.basename(src), ())
+    deps = [src] + [hd for hd in HEADERS if os.path.basename(hd) not in skip]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
 def build_library(force=False, verbose=False, out=None):

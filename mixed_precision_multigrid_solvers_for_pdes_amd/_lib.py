@@ -47,7 +47,11 @@ class MgStats(C.Structure):
         ("solve_seconds", C.c_double), ("h2d_seconds", C.c_double), ("d2h_seconds", C.c_double),
         ("initial_residual", C.c_double),
         ("precision_switches", C.c_int32), ("last_coarse_sweeps", C.c_int32),
+        ("switch_reason", C.c_int32), ("fp32_floor", C.c_double),
     ]
+
+
+SWITCH_REASONS = {0: None, 1: "threshold", 2: "stagnation", 3: "fp32_floor", 4: "fp32_skipped"}
 
 
 class MgPlanOp(C.Structure):
@@ -114,8 +118,9 @@ SIGNATURES = {
     "mg_dev_convert": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mg_dev_down_leg": (_i, [_i] * 11 + [_d] * 4 + [_i] * 3 + [_vp] * 5 + [_i, C.POINTER(C.c_int)]),
     "mg_dev_up_leg": (_i, [_i] * 13 + [_d] * 4 + [_i] * 2 + [_vp] * 4 + [_i] * 5 + [_vp] * 3),
-    "mg_dev_down_leg_var": (_i, [_i] * 11 + [_d] * 4 + [_i] * 3 + [_vp] * 5 + [_i, C.POINTER(C.c_int), _vp]),
-    "mg_dev_up_leg_var": (_i, [_i] * 13 + [_d] * 4 + [_i] * 2 + [_vp] * 4 + [_i] * 5 + [_vp] * 4),
+    "mg_dev_down_leg_var": (_i, [_i] * 11 + [_d] * 4 + [_i] * 3 + [_vp] * 5 + [_i, C.POINTER(C.c_int), _vp, _vp]),
+    "mg_dev_up_leg_var": (_i, [_i] * 13 + [_d] * 4 + [_i] * 2 + [_vp] * 4 + [_i] * 5 + [_vp] * 5),
+    "mg_dev_var_rdiag": (_i, [_i] * 4 + [_d] * 3 + [_vp] * 3),
     "mg_dev_inject_ring": (_i, [_i] * 11 + [_vp] * 3),
     "mg_dev_scratch_bytes": (_i, [_i, _i, C.POINTER(C.c_int64)]),
     "mg_pitch_elems": (_i, [_i, _i, _pi]),

@@ -60,6 +60,7 @@ struct Level {
   void* rhs[2] = {nullptr, nullptr};
   void* r[2] = {nullptr, nullptr};     // residual
   void* a[2] = {nullptr, nullptr};     // diffusion coefficient (variable-coefficient operator), else null
+  void* rd[2] = {nullptr, nullptr};    // its reciprocal diagonal 1 / D per cell (var_rdiag_kernel): what the sweeps multiply by
   double timings[3] = {0, 0, 0};       // smooth / restrict / prolong seconds (cfg.profile)
 };
 
@@ -91,9 +92,12 @@ struct mg_handle {
   int grid_dtype = MG_F64;      // the reference Grid's dtype: MG_F32 only for MG_PREC_SINGLE
   int phase = MG_F64;           // working precision of the adaptive policy
   bool promoted = false;        // one-way rule: fp32 -> fp64 happened
+  double fp32_floor = 0.0;      // adaptive policy: eps32 * diag(A) * ||u||_h of the current solve's fp32 phase (0: not evaluated)
+  int switch_reason = 0;        // why the fp32 phase of the current solve ended (mg_stats.switch_reason)
   bool have_rhs = false;
   bool varcoef = false;          // A = coeff * div(a grad .) with the per-level fields lv[l].a
   double sigma = 0.0;            // Helmholtz shift: A = coeff * (Laplacian - sigma I) on every level (mg_set_shift)
+  double rd_sigma = -1.0;        // the shift the reciprocal diagonals lv[l].rd were computed for (< 0: stale)
   double ring_sumsq[2] = {0, 0};   // sum of f^2 over the boundary ring of the fine rhs, per dtype (r = f there)
   unsigned rhs_gen = 1;            // bumped by every new right-hand side
   unsigned rings_gen[2] = {0, 0};  // rhs_gen the coarse rhs rings of working precision p were injected for (adaptive policy)

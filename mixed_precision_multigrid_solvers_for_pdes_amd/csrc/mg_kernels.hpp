@@ -667,7 +667,7 @@ __global__ __launch_bounds__(kBlock) void coarse_lexgs_kernel(T* __restrict__ u,
           const T aip = T(0.5) * (q[0] + q[ld]), aim = T(0.5) * (q[0] + q[-ld]), ajp = T(0.5) * (q[0] + q[1]), ajm = T(0.5) * (q[0] + q[-1]);
           const T nb = (aip * p[ld] + aim * p[-ld]) / hx2 + (ajp * p[1] + ajm * p[-1]) / hy2;
           const T D = (aip + aim) / hx2 + (ajp + ajm) / hy2 + sigma;
-          const T un = (rhs[(size_t)i * ld + j] + nb) / D;
+          const T un = (rhs[(size_t)i * ld + j] + nb) * (T(1) / D);          // variable coefficient: times the reciprocal diagonal
           p[0] = one_m_omega * p[0] + omega * un;
           continue;
         }
@@ -769,6 +769,7 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
     aip = T(0.5) * (ac + sa[g + ny]); aim = T(0.5) * (ac + sa[g - ny]); ajp = T(0.5) * (ac + sa[g + 1]); ajm = T(0.5) * (ac + sa[g - 1]);
     Dv = (exact ? (aip + aim) * rhx2 + (ajp + ajm) * rhy2 : (aip + aim) / hx2 + (ajp + ajm) / hy2) + sigma;
   }
+  const T rDv = T(1) / Dv;                        // VAR: the smoothers multiply by the reciprocal diagonal (oracle: _var_update)
   T h0 = uv, h1 = uv, h2 = uv;                    // the lane's last three sweep values, newest first
   int tnext = 2 + d, knext = 1;
   int kc = 1, tdone = 2 + 6;
@@ -787,7 +788,7 @@ __device__ int lexgs_pipelined_5x5(T* __restrict__ su, const T* __restrict__ sf,
       const T sx = VAR ? aip * dn + aim * up : dn + up, sy = VAR ? ajp * rt + ajm * lf : rt + lf;
       const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
       const T num = fv + nb;
-      const T un = VAR ? num / Dv : (exact ? num * rdiag : num / diag);
+      const T un = VAR ? num * rDv : (exact ? num * rdiag : num / diag);
       const T nv = one_m_omega * uv + omega * un;
       if (mine && t == tnext && knext <= maxit) {
         uv = nv;
@@ -860,6 +861,7 @@ __device__ int lexgs_5x5_zero_ring(T* __restrict__ su, const T* __restrict__ sf,
     aip = T(0.5) * (ac + sa[g + ny]); aim = T(0.5) * (ac + sa[g - ny]); ajp = T(0.5) * (ac + sa[g + 1]); ajm = T(0.5) * (ac + sa[g - 1]);
     Dv = (EXACT ? (aip + aim) * rhx2 + (ajp + ajm) * rhy2 : (aip + aim) / hx2 + (ajp + ajm) / hy2) + sigma;
   }
+  const T rDv = T(1) / Dv;
   const bool even = mine && !(d & 1), odd = mine && (d & 1);
   const bool lead1 = mine && (d == 3 || d == 4), lead2 = mine && d == 2;   // sweeps ahead of the sweep under test
   auto step = [&](bool upd) {
@@ -868,7 +870,7 @@ __device__ int lexgs_5x5_zero_ring(T* __restrict__ su, const T* __restrict__ sf,
     const T sx = VAR ? aip * dn + aim * up : dn + up, sy = VAR ? ajp * rt + ajm * lf : rt + lf;
     const T nb = EXACT ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
     const T num = fv + nb;
-    const T un = VAR ? num / Dv : (EXACT ? num * rdiag : num / diag);
+    const T un = VAR ? num * rDv : (EXACT ? num * rdiag : num / diag);
     const T nv = one_m_omega * uv + omega * un;
     uv = upd ? nv : uv;
   };
@@ -982,6 +984,7 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
     T uv = interior ? su[c] : T(0);
     T aip = T(1), aim = T(1), ajp = T(1), ajm = T(1), Dv = diag;
     if (VAR && interior) faces(c, aip, aim, ajp, ajm, Dv);
+    const T rDv = T(1) / Dv;
     int tnext = 2 + ci + cj;            // time of this cell's next update: 2k + d with k = 1
     int knext = 1;
     T* hslot = hist + c;                // snapshot slot of sweep knext (slot index knext % H, advanced incrementally)
@@ -996,7 +999,7 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
         const T sy = VAR ? ajp * su[c + 1] + ajm * su[c - 1] : su[c + 1] + su[c - 1];
         const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
         const T num = fv + nb;
-        const T un = VAR ? num / Dv : (exact ? num * rdiag : num / diag);
+        const T un = VAR ? num * rDv : (exact ? num * rdiag : num / diag);
         uv = one_m_omega * uv + omega * un;
         su[c] = uv;
         *hslot = uv;
@@ -1042,7 +1045,7 @@ __device__ int lexgs_pipelined(T* __restrict__ su, const T* __restrict__ sf, T* 
       const T sy = VAR ? ajp * su[c + 1] + ajm * su[c - 1] : su[c + 1] + su[c - 1];
       const T nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
       const T num = sf[c] + nb;
-      const T un = VAR ? num / Dv : (exact ? num * rdiag : num / diag);
+      const T un = VAR ? num * (T(1) / Dv) : (exact ? num * rdiag : num / diag);
       const T v = one_m_omega * su[c] + omega * un;
       su[c] = v;
       hist[(k % H) * ncell + c] = v;
@@ -1155,7 +1158,9 @@ __global__ __launch_bounds__(64) void coarse_lexgs_small_kernel(T* __restrict__ 
 //   Discretisation: vertex values a[i][j]; face values by arithmetic mean, a(i+1/2,j) = 0.5 (a[i][j] + a[i+1][j]);
 //     sx = a(i+1/2) u[i+1] + a(i-1/2) u[i-1],  sy likewise in j,  D = (a(i+1/2)+a(i-1/2))/hx^2 + (a(j+1/2)+a(j-1/2))/hy^2
 //     A u   = coeff * ((sx/hx^2 + sy/hy^2) - u D)            residual r = f - A u (boundary r = f)
-//     Jacobi: un = (f + sx/hx^2 + sy/hy^2) / D ; u' = (1-w) u + w un ; red-black GS the same per colour, in place.
+//     Jacobi: un = (f + sx/hx^2 + sy/hy^2) * (1 / D) ; u' = (1-w) u + w un ; red-black GS the same per colour, in place.
+//       (round 3: times the reciprocal diagonal, rounded once -- it depends on a only, and the fused legs read it from a
+//       field of its own (var_rdiag_kernel), so no sweep divides; until round 2 the sweeps divided by D)
 //   Coarse operators: re-discretisation with a injected to the coarse vertices.
 //   One kernel, four modes; u and a tiles (+1-cell halo) staged in LDS (37 KB -> 4 workgroups / CU); 4w / DoF.
 // ============================================================================================
@@ -1220,7 +1225,7 @@ __global__ __launch_bounds__(kBlock) void varcoef_kernel(const T* u_in, const T*
       const bool interior = row_in && gj >= 1 && gj < g.ny - 1;
       if (MODE == kVarJacobi || MODE == kVarRbgs) {
         const T nb = ihx2 * sx + ihy2 * sy;
-        const T un = (f[k].v[e] + nb) / D;
+        const T un = (f[k].v[e] + nb) * (T(1) / D);      // times the reciprocal diagonal (the fused legs read it from the level's rdiag field)
         const T res = one_m_omega * mid.v[e] + omega * un;
         const bool mine = (MODE == kVarJacobi) || (((gi + gj + poff) & 1) == colour);
         o.v[e] = (interior && mine) ? res : mid.v[e];
@@ -1236,6 +1241,26 @@ __global__ __launch_bounds__(kBlock) void varcoef_kernel(const T* u_in, const T*
   if (MODE == kVarResidualNorm) {
     const double t = block_reduce_sum(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
+// Reciprocal diagonal of the variable-coefficient operator, one value per cell: rd = 1 / D with D exactly as the residual
+// stages form it -- (aip + aim) ihx2 + (ajp + ajm) ihy2 [+ sigma], face means 0.5 (a_c + a_nb) -- rounded ONCE in the level's
+// dtype; 0 on boundary cells.  Recomputed when the coefficient or the shift changes; every sweep multiplies by it.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void var_rdiag_kernel(const T* __restrict__ a, T* __restrict__ rd, int nx, int ny, int ld, T ihx2,
+                                                           T ihy2, T sigma) {
+  const long long total = (long long)nx * ny;
+  for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < total; v += (long long)gridDim.x * kBlock) {
+    const int i = (int)(v / ny), j = (int)(v - (long long)i * ny);
+    T out = T(0);
+    if (i >= 1 && i < nx - 1 && j >= 1 && j < ny - 1) {
+      const T* q = a + (size_t)i * ld + j;
+      const T aip = T(0.5) * (q[0] + q[ld]), aim = T(0.5) * (q[0] + q[-ld]), ajp = T(0.5) * (q[0] + q[1]), ajm = T(0.5) * (q[0] + q[-1]);
+      const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
+      out = T(1) / ((sigma != T(0)) ? D0 + sigma : D0);
+    }
+    rd[(size_t)i * ld + j] = out;
   }
 }
 
@@ -1296,7 +1321,7 @@ __device__ __forceinline__ T tail_var_un(const T* __restrict__ src, const T* __r
   const T ajp = T(0.5) * (ac + A[idx + 1]), ajm = T(0.5) * (ac + A[idx - 1]);
   const T sx = aip * src[idx + ny] + aim * src[idx - ny], sy = ajp * src[idx + 1] + ajm * src[idx - 1];
   const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
-  return (fv + (ihx2 * sx + ihy2 * sy)) / ((sigma != T(0)) ? D0 + sigma : D0);
+  return (fv + (ihx2 * sx + ihy2 * sy)) * (T(1) / ((sigma != T(0)) ? D0 + sigma : D0));
 }
 
 template <typename T, bool VAR>
@@ -1515,7 +1540,7 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
               const TCO sy = VAR ? ajp * su[idx + 1] + ajm * su[idx - 1] : su[idx + 1] + su[idx - 1];
               const TCO nb = exact ? sx * rhx2 + sy * rhy2 : sx / hx2 + sy / hy2;
               const TCO num = sf[idx] + nb;
-              const TCO un = VAR ? num / Dv : (exact ? num * rdiag : num / diag);
+              const TCO un = VAR ? num * (TCO(1) / Dv) : (exact ? num * rdiag : num / diag);
               su[idx] = TCO(0) * su[idx] + TCO(1) * un;      // omega = 1: (1-w)*u + w*un, as the reference evaluates it
             }
             __builtin_amdgcn_wave_barrier();
@@ -1686,7 +1711,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
     double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 (interior cells) per block
     FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff,
     const T* __restrict__ acoef,          // VAR: vertex values of the diffusion coefficient (same shape / pitch as u)
-    T sigma) {                            // VAR: Helmholtz shift added to the per-cell diagonal (constant path: folded into D)
+    T sigma,                              // VAR: Helmholtz shift added to the per-cell diagonal (constant path: folded into D)
+    const T* __restrict__ rdiag) {        // VAR: reciprocal diagonal 1 / ((aip + aim) ihx2 + (ajp + ajm) ihy2 [+ sigma]) per cell (var_rdiag_kernel)
   using S = FusedShape<T, HALO, TI>;
   constexpr int N = S::N;
   __shared__ __attribute__((aligned(16))) T bufA[S::ELEMS];
@@ -1714,7 +1740,16 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
   constexpr int AVK = VAR ? S::RPT + 1 : 1, AVN = VAR ? N : 1, AHK = VAR ? S::RPT : 1, AHN = VAR ? N + 1 : 1;
   T av[AVK][AVN];     // av[k][e]: face between rows r_base + k - 1 and r_base + k     (a(i-1/2) of row k, a(i+1/2) of row k - 1)
   T ah[AHK][AHN];     // ah[k][e]: face between columns lc + e - 1 and lc + e of row r_base + k
+  T rdv[AHK][AVN];    // rdv[k][e]: reciprocal diagonal of the thread's cells (the level's rdiag field)
   if (VAR) {
+#pragma unroll
+    for (int k = 0; k < S::RPT; ++k) {
+      const int r = r_base + k, gi = ri0 + r;
+      Pack<T> p = zero_pack<T>();
+      if (worker && r < S::RI && gi >= 0 && gi < a.nx && gj0 >= 0 && gj0 < a.nyv) p = ldg(rdiag + (size_t)gi * a.ld + gj0);
+#pragma unroll
+      for (int e = 0; e < AVN; ++e) rdv[VAR ? k : 0][VAR ? e : 0] = p.v[VAR ? e : 0];
+    }
 #pragma unroll
     for (int k = 0; k < S::RPT; ++k) {
       const int r = r_base + k, gi = ri0 + r;
@@ -1836,8 +1871,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
               const T aip = av[VAR ? k + 1 : 0][VAR ? e : 0], aim = av[VAR ? k : 0][VAR ? e : 0];
               const T ajp = ah[VAR ? k : 0][VAR ? e + 1 : 0], ajm = ah[VAR ? k : 0][VAR ? e : 0];
               const T sx = aip * dn.v[e] + aim * up.v[e], sy = ajp * ea + ajm * w;
-              const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
-              un = (f[k].v[e] + (ihx2 * sx + ihy2 * sy)) / ((sigma != T(0)) ? D0 + sigma : D0);
+              un = (f[k].v[e] + (ihx2 * sx + ihy2 * sy)) * rdv[VAR ? k : 0][VAR ? e : 0];
             } else {
               const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
               un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;
@@ -1874,8 +1908,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_jacobi_kernel(
               const T aip = av[VAR ? k + 1 : 0][VAR ? e : 0], aim = av[VAR ? k : 0][VAR ? e : 0];
               const T ajp = ah[VAR ? k : 0][VAR ? e + 1 : 0], ajm = ah[VAR ? k : 0][VAR ? e : 0];
               const T sx = aip * dn.v[e] + aim * up.v[e], sy = ajp * ea + ajm * w;
-              const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
-              un = (f[k].v[e] + (ihx2 * sx + ihy2 * sy)) / ((sigma != T(0)) ? D0 + sigma : D0);
+              un = (f[k].v[e] + (ihx2 * sx + ihy2 * sy)) * rdv[VAR ? k : 0][VAR ? e : 0];
             } else {
               const T nb = ihx2 * (dn.v[e] + up.v[e]) + ihy2 * (ea + w);
               un = a.use_div ? (f[k].v[e] + nb) / D : (f[k].v[e] + nb) * invD;

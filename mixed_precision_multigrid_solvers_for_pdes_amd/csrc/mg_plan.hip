@@ -429,14 +429,14 @@ int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
       case MG_PLAN_DOWN_LEG: {
         const int rc = mg_dev_down_leg_var(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], o.d[0], o.d[1], o.d[2],
                                            o.d[3], i[11], i[12], i[13], o.p[0], o.p[1], o.p[2], o.p[3], s, i[14],
-                                           i[15] ? &i[16] : nullptr, o.p[4]);
+                                           i[15] ? &i[16] : nullptr, o.p[4], o.p[5]);
         if (rc != MG_OK) return lib_fail(rc, static_cast<int>(k), "down leg");
         break;
       }
       case MG_PLAN_UP_LEG: {
         const int rc = mg_dev_up_leg_var(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], o.d[0], o.d[1],
                                          o.d[2], o.d[3], i[13], i[14], o.p[0], o.p[1], o.p[2], o.p[3], i[15], i[16], i[17], i[18], i[19],
-                                         o.p[4], static_cast<double*>(o.p[5]), s, o.p[6]);
+                                         o.p[4], static_cast<double*>(o.p[5]), s, o.p[6], o.p[7]);
         if (rc != MG_OK) return lib_fail(rc, static_cast<int>(k), "up leg");
         break;
       }

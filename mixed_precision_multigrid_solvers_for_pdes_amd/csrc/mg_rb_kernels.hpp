@@ -153,7 +153,8 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
                                             const TX* __restrict__ e_coarse, TX* __restrict__ rhs_coarse,
                                             double* __restrict__ partials, const FusedArgs& a, T ihx2, T ihy2, T invD, T D, T omega,
                                             T one_m_omega, T coeff, Pack<T>* __restrict__ xbuf, TX* __restrict__ patch,
-                                            double* __restrict__ red, int i0, int j0, const T* __restrict__ acoef, T sigma) {
+                                            double* __restrict__ red, int i0, int j0, const T* __restrict__ acoef, T sigma,
+                                            const T* __restrict__ rdiag) {
   using S = RbShape<T, HALO, W, RPT>;
   constexpr int N = S::N;
   constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
@@ -188,13 +189,18 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
   constexpr int AVK = VAR ? RPT + 1 : 1, AHK = VAR ? RPT : 1, AHN = VAR ? N + 1 : 1;
   Pack<T> av[AVK];            // av[k]: faces between strip rows k - 1 and k (a(i-1/2) of row k, a(i+1/2) of row k - 1)
   T ah[AHK][AHN];             // ah[k][e]: face between the lane's cells e - 1 and e of row k (e = 0 / N: towards the neighbour lane)
+  Pack<T> RD[AHK];            // RD[k]: reciprocal diagonal of the lane's cells of row k (the level's rdiag field: no division in the sweeps)
   if (VAR) {
     Pack<T> A[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const int gi = ri0 + r_base + k;
       A[k] = zero_pack<T>();
-      if (INT || (gi >= 0 && gi < a.nx && col_in)) A[k] = ldg(acoef + (size_t)gi * a.ld + gj0);
+      RD[VAR ? k : 0] = zero_pack<T>();
+      if (INT || (gi >= 0 && gi < a.nx && col_in)) {
+        A[k] = ldg(acoef + (size_t)gi * a.ld + gj0);
+        RD[VAR ? k : 0] = ldg(rdiag + (size_t)gi * a.ld + gj0);
+      }
     }
     Pack<T> a_above, a_below;
     rb_exchange<T, W>(xbuf + (size_t)W * 2 * 64, w, lane, A[0], A[RPT - 1], a_above, a_below);      // buffer 1: the first sweep uses buffer 0
@@ -263,53 +269,56 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
     Pack<T> above, below;
     rb_exchange<T, W>(xbuf + (size_t)(stage & 1) * W * 2 * 64, w, lane, U[0], U[RPT - 1], above, below);
     const int colour = s & 1;
-    // parity of (gi + gj + colour_offset) for strip row 0, cell 0: rows and cells alternate from there
-    const int par0 = (ri0 + r_base + gj0 + a.colour_offset) & 1;
-    Pack<T> prev = above;                         // the (old) row above the one being updated
+    // parity of (gi + gj + colour_offset) for strip row 0, cell 0: rows and cells alternate from there.  r_base = w RPT and
+    // lane N are even, so the parity is the workgroup's: a scalar, and the branch on it below is not divergent
+    static_assert(N % 2 == 0 && RPT % 2 == 0, "strip rows / lane cells must be even for a workgroup-uniform colour parity");
+    const int par0 = (ri0 + rj0 + a.colour_offset) & 1;
+    // one pass over the strip.  QP (red-black GS): compile-time parity of the pass -- cell e of strip row k is of the colour
+    // being updated iff (QP + k + e) is even, so a variable-coefficient pass spends its arithmetic on those cells only
+    // (constant coefficients: the packed row arithmetic computes both colours for the price of one)
+    auto pass = [&](auto qp) {
+      constexpr int QP = decltype(qp)::value;
+      Pack<T> prev = above;                       // the (old) row above the one being updated
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const int r = r_base + k, gi = ri0 + r;
-      const Pack<T> mid = U[k];
-      const Pack<T> dn = (k < RPT - 1) ? U[k + 1] : below;
-      const T left = dpp_from_lower_lane<T>(mid.v[N - 1]);       // every lane active here
-      const T right = dpp_from_upper_lane<T>(mid.v[0]);
-      Pack<T> o = mid;
-      const bool row_ok = INT ? ((k > 0 || w > 0) && (k < RPT - 1 || w < W - 1))
-                              : (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1);
-      if (row_ok && !VAR) {
-        const Pack<T> res = RowMath<T, N>::relax(mid, dn, prev, left, right, F[k], ihx2, ihy2, invD, D, omega, one_m_omega, a.use_div != 0);
+      for (int k = 0; k < RPT; ++k) {
+        const int r = r_base + k, gi = ri0 + r;
+        const Pack<T> mid = U[k];
+        const Pack<T> dn = (k < RPT - 1) ? U[k + 1] : below;
+        const T left = dpp_from_lower_lane<T>(mid.v[N - 1]);       // every lane active here
+        const T right = dpp_from_upper_lane<T>(mid.v[0]);
+        Pack<T> o = mid;
+        const bool row_ok = INT ? ((k > 0 || w > 0) && (k < RPT - 1 || w < W - 1))
+                                : (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1);
+        if (row_ok && !VAR) {
+          const Pack<T> res = RowMath<T, N>::relax(mid, dn, prev, left, right, F[k], ihx2, ihy2, invD, D, omega, one_m_omega, a.use_div != 0);
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-          const int gj = gj0 + e;
-          const bool mine = (SM != kSmRbgs) || (((par0 + k + e) & 1) == colour);
-          if ((INT || (gj >= 1 && gj < a.ny - 1)) && mine) o.v[e] = res.v[e];
+          for (int e = 0; e < N; ++e) {
+            const int gj = gj0 + e;
+            const bool mine = (SM != kSmRbgs) || (((QP + k + e) & 1) == 0);
+            if ((INT || (gj >= 1 && gj < a.ny - 1)) && mine) o.v[e] = res.v[e];
+          }
         }
-      }
-      if (row_ok && VAR) {
+        if (row_ok && VAR) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-          const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
-          const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
-          T un;
-          if (VAR) {
+          for (int e = 0; e < N; ++e) {
+            if (SM == kSmRbgs && ((QP + k + e) & 1) != 0) continue;
+            const T wv = (e == 0) ? left : mid.v[e > 0 ? e - 1 : 0];
+            const T ea = (e == N - 1) ? right : mid.v[e < N - 1 ? e + 1 : 0];
             const T aip = av[VAR ? k + 1 : 0].v[e], aim = av[VAR ? k : 0].v[e];
             const T ajp = ah[VAR ? k : 0][VAR ? e + 1 : 0], ajm = ah[VAR ? k : 0][VAR ? e : 0];
             const T sx = aip * dn.v[e] + aim * prev.v[e], sy = ajp * ea + ajm * wv;
-            const T D0 = (aip + aim) * ihx2 + (ajp + ajm) * ihy2;
-            un = (F[k].v[e] + (ihx2 * sx + ihy2 * sy)) / ((sigma != T(0)) ? D0 + sigma : D0);
-          } else {
-            const T nb = ihx2 * (dn.v[e] + prev.v[e]) + ihy2 * (ea + wv);
-            un = a.use_div ? (F[k].v[e] + nb) / D : (F[k].v[e] + nb) * invD;
+            const T un = (F[k].v[e] + (ihx2 * sx + ihy2 * sy)) * RD[VAR ? k : 0].v[e];
+            const T res = one_m_omega * mid.v[e] + omega * un;
+            const int gj = gj0 + e;
+            if (INT || (gj >= 1 && gj < a.ny - 1)) o.v[e] = res;
           }
-          const T res = one_m_omega * mid.v[e] + omega * un;
-          const int gj = gj0 + e;
-          const bool mine = (SM != kSmRbgs) || (((par0 + k + e) & 1) == colour);
-          if ((INT || (gj >= 1 && gj < a.ny - 1)) && mine) o.v[e] = res;
         }
+        U[k] = o;
+        prev = (SM == kSmRbgs) ? o : mid;         // red-black GS is in place: the neighbours it reads are not of this colour
       }
-      U[k] = o;
-      prev = (SM == kSmRbgs) ? o : mid;           // red-black GS is in place: the neighbours it reads are not of this colour
-    }
+    };
+    if (SM == kSmRbgs && ((par0 + colour) & 1) != 0) pass(std::integral_constant<int, 1>{});
+    else pass(std::integral_constant<int, 0>{});
   }
 
   // ---- write the tile of u' ------------------------------------------------------------------------------------------
@@ -419,14 +428,19 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
 
 template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int TAG, int SM, int W, int RPT,
           bool VAR = false>
-__global__ __launch_bounds__(W * 64) void rb_leg_kernel(
+// VAR, fp64: the face means and the reciprocal diagonal are 44 more registers per lane; left alone the compiler takes 131-137
+// in some variants and ONE 8-wave workgroup fits a CU (the up leg ran 256 us at 4097^2, 180 with two).  Four waves per
+// SIMD (<= 128 registers, 4-13 of them spilled) keeps two workgroups resident.  fp32 (148-191 registers) spills 40-130
+// under the same cap and loses 20-60 %: left alone.
+__global__ __launch_bounds__(W * 64, (VAR && sizeof(T) == 8) ? 4 : 1) void rb_leg_kernel(
     const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
     const TX* __restrict__ e_coarse,      // PROLONG: coarse correction (dtype TX)
     TX* __restrict__ rhs_coarse,          // POST == kPostRestrict: coarse rhs (dtype TX)
     double* __restrict__ partials,        // POST == kPostNorm: one partial sum of r^2 per block
     FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff,
     const T* __restrict__ acoef,          // VAR: vertex values of the diffusion coefficient (shape / pitch of u)
-    T sigma) {                            // VAR: Helmholtz shift added to the per-cell diagonal
+    T sigma,                              // VAR: Helmholtz shift added to the per-cell diagonal
+    const T* __restrict__ rdiag) {        // VAR: reciprocal diagonal per cell (var_rdiag_kernel)
   using S = RbShape<T, HALO, W, RPT>;
   constexpr int N = S::N;
   constexpr int kNT = (TAG == 2) ? MG_RB_NT_MODE : 0;           // TAG 2: the streaming-hint variant for arrays beyond the Infinity Cache
@@ -464,11 +478,11 @@ __global__ __launch_bounds__(W * 64) void rb_leg_kernel(
   if (interior)
     rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, true, kNT, VAR>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2,
                                                                                 invD, D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0,
-                                                                                acoef, sigma);
+                                                                                acoef, sigma, rdiag);
   else
     rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, false, kNT, VAR>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2,
                                                                                  invD, D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0,
-                                                                                 acoef, sigma);
+                                                                                 acoef, sigma, rdiag);
 }
 
 }  // namespace mg

@@ -2,6 +2,7 @@
 #include "mg_host.hpp"
 #include "mg_tail_kernels.hpp"
 
+#include <cmath>
 #include <cstring>
 
 namespace mgh {
@@ -20,10 +21,10 @@ bool dyadic_square_tail(const mg_handle* h, int k) {
   return true;
 }
 
-template <typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV>
+template <typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV, bool VAR = false>
 int launch_d(mg_handle* h, const mg::Tail2Args& a, const void* rhs, void* u, bool zero_top) {
   using L = mg::T2Lds<T, TCO, NCTOP>;
-  auto k = mg::tail2_kernel<T, TCO, TC, SM, NCTOP, DIV>;
+  auto k = mg::tail2_kernel<T, TCO, TC, SM, NCTOP, DIV, VAR>;
   static bool attr_done = false;                       // per instantiation
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::kTotal) != hipSuccess)
@@ -39,6 +40,13 @@ int launch_d(mg_handle* h, const mg::Tail2Args& a, const void* rhs, void* u, boo
 // level multiplies by the exact 1 / D (bit-identical to the division)
 template <typename T, typename TCO, typename TC, int SM, int NCTOP>
 int launch_t(mg_handle* h, const mg::Tail2Args& a, const void* rhs, void* u, bool zero_top) {
+  if (h->varcoef) {
+    // variable coefficients: every sweep multiplies by the stored reciprocal diagonal (no DIV variant); the coefficient
+    // registers of a 65^2 top level do not fit beside the iterate (fp64: 236 registers before any temporary; fp32 spills
+    // 15..80 of them to scratch), so these hierarchies enter at 33^2 (tail2_plan)
+    if constexpr (NCTOP == 64) return MG_ERR_INVALID_VALUE;
+    else return launch_d<T, TCO, TC, SM, NCTOP, false, true>(h, a, rhs, u, zero_top);
+  }
   bool div = false;
   for (int l = h->tail2_start; l <= h->L() - 2; ++l) div = div || !coefs(h->lv[l].hx, h->lv[l].hy, h->sigma).pow2;
   return div ? launch_d<T, TCO, TC, SM, NCTOP, true>(h, a, rhs, u, zero_top) : launch_d<T, TCO, TC, SM, NCTOP, false>(h, a, rhs, u, zero_top);
@@ -62,19 +70,19 @@ int launch_sm(mg_handle* h, const mg::Tail2Args& a, const void* rhs, void* u, bo
 
 }  // namespace
 
-// The register-resident tail serves constant-coefficient hierarchies whose last levels are the dyadic squares 65 / 33 /
-// 17 / 9 / 5 in one precision (the coarsest level in the grid dtype): every 2^k + 1 grid on a square domain.  Everything
-// else -- rectangles, non-dyadic cell counts, a coarsest grid that is not 5 x 5, variable coefficients -- stays with
-// coarse_tail_kernel (plan_tail in mghip.hip).  mg_config.tail: 1 (default) this kernel where it applies, 2 the LDS tail
-// only (A/B runs and tests of that kernel).
+// The register-resident tail serves hierarchies whose last levels are the dyadic squares 65 / 33 / 17 / 9 / 5 in one
+// precision (the coarsest level in the grid dtype): every 2^k + 1 grid on a square domain, constant or variable
+// coefficient (the latter from 33^2 down: the face means and the reciprocal diagonal live in registers beside the iterate).  Everything else -- rectangles, non-dyadic cell counts, a coarsest grid that is not
+// 5 x 5 -- stays with coarse_tail_kernel (plan_tail in mghip.hip).  mg_config.tail: 1 (default) this kernel where it
+// applies, 2 the LDS tail only (A/B runs and tests of that kernel).
 int tail2_plan(mg_handle* h) {
   h->tail2_start = -1;
   h->tail2_ntop = 0;
   const int L = h->L();
-  if (h->cfg.tail != 1 || !h->fused() || L < 3 || h->varcoef) return MG_OK;
+  if (h->cfg.tail != 1 || !h->fused() || L < 3) return MG_OK;
   for (int k = 1; k <= L - 3; ++k) {                    // at least 17^2 -> 9^2 -> 5^2
     const int n = h->lv[k].nx;
-    if (n > 65) continue;
+    if (n > (h->varcoef ? 33 : 65)) continue;
     if (!dyadic_square_tail(h, k)) return MG_OK;
     bool uniform = true;
     for (int l = k; l <= L - 2; ++l) uniform = uniform && (h->level_dtype_in(l, MG_F64) == h->level_dtype_in(k, MG_F64));
@@ -111,12 +119,18 @@ int tail2_launch(mg_handle* h, bool zero_top) {
     if (h->cfg.cycle == MG_CYCLE_W) reps = 2;
     else if (h->cfg.cycle == MG_CYCLE_F) reps = std::max(1, 1 << std::max(0, L - l - 2));
     a.reps[l - k] = reps;
+    if (h->varcoef) { a.a_lv[l - k] = v.a[dt]; a.rd_lv[l - k] = v.rd[dt]; a.a_ld[l - k] = v.ld[dt]; }
   }
   {
     const Level& v = h->lv[L - 1];
     const Coef c = coefs(v.hx, v.hy, h->sigma);
     a.hx2_5 = v.hx * v.hx; a.hy2_5 = v.hy * v.hy; a.diag_5 = c.diag; a.hxhy_5 = v.hx * v.hy; a.exact_5 = c.all_pow2 ? 1 : 0;
     a.ring5 = v.rhs[dco]; a.ring5_ld = v.ld[dco];
+    if (h->varcoef) {    // hx^2, hy^2 powers of two are all the variable-coefficient solve needs to multiply by reciprocals
+      int e = 0;
+      a.exact_5 = (std::frexp(a.hx2_5, &e) == 0.5 && std::frexp(a.hy2_5, &e) == 0.5) ? 1 : 0;
+      a.a_lv[mg::kT2MaxLev] = v.a[dco]; a.a_ld[mg::kT2MaxLev] = v.ld[dco];
+    }
   }
   int rc;
   if (dt == MG_F64) rc = launch_sm<double, double, double>(h, a, top.rhs[dt], top.u[dt], zero_top, h->tail2_ntop);

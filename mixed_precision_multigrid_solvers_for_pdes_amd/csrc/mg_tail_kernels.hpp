@@ -55,6 +55,11 @@ struct Tail2Args {
   const void* ring5;                    // the coarsest level's rhs array in HBM (dtype TCO): its boundary ring is the injected
   int ring5_ld;                         //   ring of f, which the reference's stop test counts (solvers/base.py:271-283)
   double minv[81];                      // direct: inverse of the 9 x 9 coarsest matrix, row-major
+  // variable coefficients (VAR): vertex values of a and the reciprocal diagonal of every register level (dtype T, pitch
+  // a_ld[i]), and the 5 x 5 level's coefficient (dtype TCO)
+  const void* a_lv[kT2MaxLev + 1];
+  const void* rd_lv[kT2MaxLev];
+  int a_ld[kT2MaxLev + 1];
 };
 
 template <int NC> struct T2Geo {
@@ -140,6 +145,37 @@ __device__ __forceinline__ void t2_exchange(T* __restrict__ xb, const T2Lane& p,
   above[0] = a.v[0]; above[1] = a.v[1]; below[0] = bl.v[0]; below[1] = bl.v[1];
 }
 
+// Variable coefficients: the face means of the lane's cells -- av[k][e]: between rows k - 1 and k of column e (a(i-1/2) of
+// row k, a(i+1/2) of row k - 1), ah[k][q]: west of column 0 / between the two columns / east of column 1 -- and their
+// reciprocal diagonal (the level's rdiag field), formed once per launch and kept in registers for every visit of the level.
+template <typename T, int R> struct T2Coef { T av[R + 1][2], ah[R][3], rd[R][2]; };
+template <typename T> struct T2NoCoef {};
+
+template <typename T, int NC>
+__device__ __forceinline__ void t2_load_coef(T2Coef<T, T2Geo<NC>::R>& cf, const T2Lane& p, const T* __restrict__ a, const T* __restrict__ rd,
+                                             int ld) {
+  constexpr int R = T2Geo<NC>::R;
+  T A[R + 2][4];                                     // rows R s - 1 .. R s + R, columns 2 lc - 1 .. 2 lc + 2 (clamped at 0)
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = max(R * p.strip - 1 + r, 0), j = max(2 * p.lc - 1 + q, 0);
+      A[r][q] = p.active ? a[(size_t)i * ld + j] : T(0);
+    }
+#pragma unroll
+  for (int k = 0; k <= R; ++k)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) cf.av[k][e] = T(0.5) * (A[k + 1][e + 1] + A[k][e + 1]);
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) cf.ah[k][q] = T(0.5) * (A[k + 1][q + 1] + A[k + 1][q]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) cf.rd[k][e] = p.active ? rd[(size_t)(R * p.strip + k) * ld + 2 * p.lc + e] : T(0);
+  }
+}
+
 // Per-level constants.  They are wave-uniform, but kept in VECTOR registers on purpose (t2_pin): as kernel arguments the
 // compiler re-loads them with s_load inside the sweep loops whenever scalar registers run short -- a ~200-cycle round trip
 // per stage of a kernel whose stages are a few hundred cycles long.
@@ -151,9 +187,9 @@ template <typename T> __device__ __forceinline__ T t2_pin(T x) {
 
 // One weighted-Jacobi sweep.  DIV: divide by the diagonal (the reference's expression; needed when 1 / D is not exact), else
 // multiply by the exact 1 / D.  Written layer by layer over the 2 R cells of the lane.
-template <typename T, int NC, bool DIV>
+template <typename T, int NC, bool DIV, bool VAR, typename CF>
 __device__ __forceinline__ void t2_jacobi(T (&U)[T2Geo<NC>::R][2], const T (&F)[T2Geo<NC>::R][2], T* __restrict__ xbuf, int& stage,
-                                          const T2Lane& p, const T2Const<T>& c) {
+                                          const T2Lane& p, const T2Const<T>& c, const CF& cf) {
   using G = T2Geo<NC>;
   constexpr int R = G::R;
   T above[2], below[2];
@@ -168,10 +204,16 @@ __device__ __forceinline__ void t2_jacobi(T (&U)[T2Geo<NC>::R][2], const T (&F)[
     for (int e = 0; e < 2; ++e) {
       const T up = (k > 0) ? U[k > 0 ? k - 1 : 0][e] : above[e];
       const T dn = (k < R - 1) ? U[k < R - 1 ? k + 1 : 0][e] : below[e];
-      sx[k][e] = dn + up;
+      if constexpr (VAR) sx[k][e] = cf.av[k + 1][e] * dn + cf.av[k][e] * up;          // aip dn + aim up
+      else sx[k][e] = dn + up;
     }
-    sy[k][0] = U[k][1] + west;                                  // (east + west)
-    sy[k][1] = east + U[k][0];
+    if constexpr (VAR) {
+      sy[k][0] = cf.ah[k][1] * U[k][1] + cf.ah[k][0] * west;    // ajp east + ajm west
+      sy[k][1] = cf.ah[k][2] * east + cf.ah[k][1] * U[k][0];
+    } else {
+      sy[k][0] = U[k][1] + west;                                // (east + west)
+      sy[k][1] = east + U[k][0];
+    }
   }
 #pragma unroll
   for (int k = 0; k < R; ++k)
@@ -192,7 +234,10 @@ __device__ __forceinline__ void t2_jacobi(T (&U)[T2Geo<NC>::R][2], const T (&F)[
 #pragma unroll
   for (int k = 0; k < R; ++k)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) sx[k][e] = DIV ? sx[k][e] / c.D : sx[k][e] * c.invD;
+    for (int e = 0; e < 2; ++e) {
+      if constexpr (VAR) sx[k][e] = sx[k][e] * cf.rd[k][e];
+      else sx[k][e] = DIV ? sx[k][e] / c.D : sx[k][e] * c.invD;
+    }
 #pragma unroll
   for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -215,9 +260,9 @@ __device__ __forceinline__ void t2_jacobi(T (&U)[T2Geo<NC>::R][2], const T (&F)[
 
 // One colour pass of red-black GS (colour 0 = (i + j + colour_offset) even first), in place.  Q = (colour + colour_offset) & 1:
 // row k updates its cell e = (Q + k) & 1 -- the same e in every lane -- from cells of the other colour only.
-template <typename T, int NC, bool DIV, int Q>
+template <typename T, int NC, bool DIV, int Q, bool VAR, typename CF>
 __device__ __forceinline__ void t2_rb_pass(T (&U)[T2Geo<NC>::R][2], const T (&F)[T2Geo<NC>::R][2], T* __restrict__ xbuf, int& stage,
-                                           const T2Lane& p, const T2Const<T>& c) {
+                                           const T2Lane& p, const T2Const<T>& c, const CF& cf) {
   using G = T2Geo<NC>;
   constexpr int R = G::R;
   T above[2], below[2];
@@ -230,10 +275,16 @@ __device__ __forceinline__ void t2_rb_pass(T (&U)[T2Geo<NC>::R][2], const T (&F)
     const int e = (e0 + k) & 1;                       // folds per unrolled k
     const T up = (k > 0) ? U[k > 0 ? k - 1 : 0][e] : above[e];
     const T dn = (k < R - 1) ? U[k < R - 1 ? k + 1 : 0][e] : below[e];
-    sx[k] = dn + up;
     // (east + west): one of the two is the lane's other column, the other one comes from the neighbour lane
-    if (e == 0) sy[k] = U[k][1] + dpp_from_lower_lane<T>(U[k][1]);
-    else sy[k] = dpp_from_upper_lane<T>(U[k][0]) + U[k][0];
+    if constexpr (VAR) {
+      sx[k] = cf.av[k + 1][e] * dn + cf.av[k][e] * up;
+      if (e == 0) sy[k] = cf.ah[k][1] * U[k][1] + cf.ah[k][0] * dpp_from_lower_lane<T>(U[k][1]);
+      else sy[k] = cf.ah[k][2] * dpp_from_upper_lane<T>(U[k][0]) + cf.ah[k][1] * U[k][0];
+    } else {
+      sx[k] = dn + up;
+      if (e == 0) sy[k] = U[k][1] + dpp_from_lower_lane<T>(U[k][1]);
+      else sy[k] = dpp_from_upper_lane<T>(U[k][0]) + U[k][0];
+    }
   }
 #pragma unroll
   for (int k = 0; k < R; ++k) sx[k] = c.ihx2 * sx[k];
@@ -244,7 +295,10 @@ __device__ __forceinline__ void t2_rb_pass(T (&U)[T2Geo<NC>::R][2], const T (&F)
 #pragma unroll
   for (int k = 0; k < R; ++k) sx[k] = F[k][(Q + k) & 1] + sx[k];
 #pragma unroll
-  for (int k = 0; k < R; ++k) sx[k] = DIV ? sx[k] / c.D : sx[k] * c.invD;
+  for (int k = 0; k < R; ++k) {
+    if constexpr (VAR) sx[k] = sx[k] * cf.rd[k][(Q + k) & 1];
+    else sx[k] = DIV ? sx[k] / c.D : sx[k] * c.invD;
+  }
 #pragma unroll
   for (int k = 0; k < R; ++k) t1[k] = c.one_m_omega * U[k][(Q + k) & 1];
 #pragma unroll
@@ -259,34 +313,35 @@ __device__ __forceinline__ void t2_rb_pass(T (&U)[T2Geo<NC>::R][2], const T (&F)
   }
 }
 
-template <typename T, int NC, int SM, bool DIV>
+template <typename T, int NC, int SM, bool DIV, bool VAR, typename CF>
 __device__ __forceinline__ void t2_smooth(T (&U)[T2Geo<NC>::R][2], const T (&F)[T2Geo<NC>::R][2], T* __restrict__ xbuf, int& stage,
-                                          const T2Lane& p, const T2Const<T>& c, int nsweep) {
+                                          const T2Lane& p, const T2Const<T>& c, const CF& cf, int nsweep) {
   if (SM == kSmRbgs) {
     if (c.coff & 1) {
 #pragma unroll 1
       for (int s = 0; s < nsweep; ++s) {
-        t2_rb_pass<T, NC, DIV, 1>(U, F, xbuf, stage, p, c);
-        t2_rb_pass<T, NC, DIV, 0>(U, F, xbuf, stage, p, c);
+        t2_rb_pass<T, NC, DIV, 1, VAR>(U, F, xbuf, stage, p, c, cf);
+        t2_rb_pass<T, NC, DIV, 0, VAR>(U, F, xbuf, stage, p, c, cf);
       }
     } else {
 #pragma unroll 1
       for (int s = 0; s < nsweep; ++s) {
-        t2_rb_pass<T, NC, DIV, 0>(U, F, xbuf, stage, p, c);
-        t2_rb_pass<T, NC, DIV, 1>(U, F, xbuf, stage, p, c);
+        t2_rb_pass<T, NC, DIV, 0, VAR>(U, F, xbuf, stage, p, c, cf);
+        t2_rb_pass<T, NC, DIV, 1, VAR>(U, F, xbuf, stage, p, c, cf);
       }
     }
   } else {
 #pragma unroll 1
-    for (int s = 0; s < nsweep; ++s) t2_jacobi<T, NC, DIV>(U, F, xbuf, stage, p, c);
+    for (int s = 0; s < nsweep; ++s) t2_jacobi<T, NC, DIV, VAR>(U, F, xbuf, stage, p, c, cf);
   }
 }
 
 // residual of the strip, then full weighting of the interior coarse cells on it; the coarse values go to fc (the coarse
 // level's n x n staging array, dtype TX) -- the caller synchronises before the coarse lanes read them
-template <typename T, typename TX, int NC>
+template <typename T, typename TX, int NC, bool VAR, typename CF>
 __device__ __forceinline__ void t2_residual_restrict(const T (&U)[T2Geo<NC>::R][2], const T (&F)[T2Geo<NC>::R][2], T* __restrict__ xbuf,
-                                                     int& stage, const T2Lane& p, const T2Const<T>& c, TX* __restrict__ fc) {
+                                                     int& stage, const T2Lane& p, const T2Const<T>& c, const CF& cf, T sigma,
+                                                     TX* __restrict__ fc) {
   using G = T2Geo<NC>;
   constexpr int R = G::R;
   constexpr int NP = NC / 2 + 1;                  // coarse points per side
@@ -304,12 +359,18 @@ __device__ __forceinline__ void t2_residual_restrict(const T (&U)[T2Geo<NC>::R][
       for (int e = 0; e < 2; ++e) {
         const T up = (k > 0) ? U[k > 0 ? k - 1 : 0][e] : above[e];
         const T dn = (k < R - 1) ? U[k < R - 1 ? k + 1 : 0][e] : below[e];
-        sx[k][e] = dn + up;
+        if constexpr (VAR) sx[k][e] = cf.av[k + 1][e] * dn + cf.av[k][e] * up;
+        else sx[k][e] = dn + up;
       }
-      sy[k][0] = U[k][1] + west;                                  // (east + west)
-      sy[k][1] = east + U[k][0];
+      if constexpr (VAR) {
+        sy[k][0] = cf.ah[k][1] * U[k][1] + cf.ah[k][0] * west;
+        sy[k][1] = cf.ah[k][2] * east + cf.ah[k][1] * U[k][0];
+      } else {
+        sy[k][0] = U[k][1] + west;                                // (east + west)
+        sy[k][1] = east + U[k][0];
+      }
     }
-    // r = f - coeff (((dn + up) ihx2 + (east + west) ihy2) - u D), layer by layer
+    // r = f - coeff (((dn + up) ihx2 + (east + west) ihy2) - u D), layer by layer (VAR: sums weighted by the face means, D per cell)
 #pragma unroll
     for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -321,7 +382,14 @@ __device__ __forceinline__ void t2_residual_restrict(const T (&U)[T2Geo<NC>::R][
 #pragma unroll
     for (int k = 0; k < R; ++k)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) md[k][e] = U[k][e] * c.D;
+      for (int e = 0; e < 2; ++e) {
+        if constexpr (VAR) {
+          const T D0 = (cf.av[k + 1][e] + cf.av[k][e]) * c.ihx2 + (cf.ah[k][e + 1] + cf.ah[k][e]) * c.ihy2;
+          md[k][e] = U[k][e] * ((sigma != T(0)) ? D0 + sigma : D0);
+        } else {
+          md[k][e] = U[k][e] * c.D;
+        }
+      }
 #pragma unroll
     for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -402,11 +470,11 @@ template <typename T, typename TCO, int NCTOP> struct T2Lds {
     return o;
   }
   static constexpr size_t off_e(int nc) { return off_f(nc) + lev_bytes(nc); }
-  static constexpr size_t kFive = off_f(4);                                           // su[25], sf[25] in TCO
-  static constexpr size_t kTotal = kFive + al(2 * 25 * sizeof(TCO));
+  static constexpr size_t kFive = off_f(4);                                           // su[25], sf[25], sa[25] (VAR) in TCO
+  static constexpr size_t kTotal = kFive + al(3 * 25 * sizeof(TCO));
 };
 
-template <typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV> struct T2Ctx {
+template <typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV, bool VAR> struct T2Ctx {
   const Tail2Args& a;
   unsigned char* pool;
   T* xbuf;
@@ -419,10 +487,11 @@ template <typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV> st
   T lvc[kT2MaxLev][4];           // ihx2, ihy2, 1 / D, D of every register level, pinned once at kernel entry (a visit that
                                  // fetched them from the kernel arguments paid an s_load round trip, ~0.3 us, every time)
   int reps[kT2MaxLev];
+  T sigma;
 };
 
 // ---- the 5 x 5 level: rhs = full weighting of the 9^2 level's residual (already in sf), solve, result in su -----------
-template <typename CX, typename T, typename TCO, int NCTOP>
+template <typename CX, typename T, typename TCO, int NCTOP, bool VAR>
 __device__ __forceinline__ void t2_solve5(CX& cx, bool zero) {
   using L = T2Lds<T, TCO, NCTOP>;
   TCO* su = reinterpret_cast<TCO*>(cx.pool + L::kFive);
@@ -451,26 +520,33 @@ __device__ __forceinline__ void t2_solve5(CX& cx, bool zero) {
     wave_lds_fence<int>();
   }
   const TCO hx2 = (TCO)a.hx2_5, hy2 = (TCO)a.hy2_5, diag = (TCO)a.diag_5, cf = (TCO)a.coeff;
+  const TCO* sa = VAR ? sf + 25 : nullptr;
+  const TCO sg = VAR ? (TCO)a.sigma : TCO(0);
   cx.sweeps = a.exact_5
-      ? lexgs_5x5_zero_ring<TCO, false, true>(su, sf, hx2, hy2, diag, cf, TCO(1), TCO(0), a.hxhy_5, a.tol_x, a.maxit, lane, nullptr, TCO(0))
-      : lexgs_5x5_zero_ring<TCO, false, false>(su, sf, hx2, hy2, diag, cf, TCO(1), TCO(0), a.hxhy_5, a.tol_x, a.maxit, lane, nullptr, TCO(0));
+      ? lexgs_5x5_zero_ring<TCO, VAR, true>(su, sf, hx2, hy2, diag, cf, TCO(1), TCO(0), a.hxhy_5, a.tol_x, a.maxit, lane, sa, sg)
+      : lexgs_5x5_zero_ring<TCO, VAR, false>(su, sf, hx2, hy2, diag, cf, TCO(1), TCO(0), a.hxhy_5, a.tol_x, a.maxit, lane, sa, sg);
 }
 
 // ---- the per-level register state: iterate and rhs of register level LI (R x 2 values each) ---------------------------
-template <typename T, int NCTOP> struct T2State {
+template <typename T, int NCTOP, bool VAR> struct T2State {
   T U0[T2Geo<NCTOP>::R][2], F0[T2Geo<NCTOP>::R][2];
   T U1[2][2], F1[2][2], U2[2][2], F2[2][2], U3[2][2], F3[2][2];     // the levels below the top have at most 32 cells per side: R = 2
+  typename std::conditional<VAR, T2Coef<T, T2Geo<NCTOP>::R>, T2NoCoef<T>>::type C0;
+  typename std::conditional<VAR, T2Coef<T, 2>, T2NoCoef<T>>::type C1, C2, C3;
 };
-template <int LI, typename T, int NCTOP> __device__ __forceinline__ auto& t2_U(T2State<T, NCTOP>& s) {
+template <int LI, typename S> __device__ __forceinline__ auto& t2_U(S& s) {
   if constexpr (LI == 0) return s.U0; else if constexpr (LI == 1) return s.U1; else if constexpr (LI == 2) return s.U2; else return s.U3;
 }
-template <int LI, typename T, int NCTOP> __device__ __forceinline__ auto& t2_F(T2State<T, NCTOP>& s) {
+template <int LI, typename S> __device__ __forceinline__ auto& t2_F(S& s) {
   if constexpr (LI == 0) return s.F0; else if constexpr (LI == 1) return s.F1; else if constexpr (LI == 2) return s.F2; else return s.F3;
+}
+template <int LI, typename S> __device__ __forceinline__ auto& t2_C(S& s) {
+  if constexpr (LI == 0) return s.C0; else if constexpr (LI == 1) return s.C1; else if constexpr (LI == 2) return s.C2; else return s.C3;
 }
 
 // ---- one visit of register level LI (NC cells per side) and everything below it ---------------------------------------
-template <int LI, int NC, typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV>
-__device__ __forceinline__ void t2_visit(T2Ctx<T, TCO, TC, SM, NCTOP, DIV>& cx, T2State<T, NCTOP>& st, bool zero) {
+template <int LI, int NC, typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV, bool VAR>
+__device__ __forceinline__ void t2_visit(T2Ctx<T, TCO, TC, SM, NCTOP, DIV, VAR>& cx, T2State<T, NCTOP, VAR>& st, bool zero) {
   using G = T2Geo<NC>;
   using L = T2Lds<T, TCO, NCTOP>;
   constexpr int R = G::R;
@@ -480,6 +556,7 @@ __device__ __forceinline__ void t2_visit(T2Ctx<T, TCO, TC, SM, NCTOP, DIV>& cx, 
   const T2Lane p = t2_lane<NC>();
   auto& U = t2_U<LI>(st);
   auto& F = t2_F<LI>(st);
+  const auto& cf = t2_C<LI>(st);
   T2Const<T> c;
   c.ihx2 = cx.lvc[LI][0]; c.ihy2 = cx.lvc[LI][1]; c.invD = cx.lvc[LI][2]; c.D = cx.lvc[LI][3];
   c.omega = cx.omega; c.one_m_omega = cx.one_m_omega; c.coeff = cx.coeff; c.coff = cx.coff;
@@ -489,17 +566,17 @@ __device__ __forceinline__ void t2_visit(T2Ctx<T, TCO, TC, SM, NCTOP, DIV>& cx, 
   }
   T2_STAMP(10 * LI + 0);
   // down leg: pre sweeps -> residual -> full weighting into the level below
-  t2_smooth<T, NC, SM, DIV>(U, F, cx.xbuf, cx.stage, p, c, cx.pre);
+  t2_smooth<T, NC, SM, DIV, VAR>(U, F, cx.xbuf, cx.stage, p, c, cf, cx.pre);
   T2_STAMP(10 * LI + 1);
   TX* fc = LAST ? reinterpret_cast<TX*>(cx.pool + L::kFive) + 25 : reinterpret_cast<TX*>(cx.pool + L::off_f(NC / 2));
   TX* ec = LAST ? reinterpret_cast<TX*>(cx.pool + L::kFive) : reinterpret_cast<TX*>(cx.pool + L::off_e(NC / 2));
-  t2_residual_restrict<T, TX, NC>(U, F, cx.xbuf, cx.stage, p, c, fc);
+  t2_residual_restrict<T, TX, NC, VAR>(U, F, cx.xbuf, cx.stage, p, c, cf, cx.sigma, fc);
   t2_sync<G::BLOCK>();
   T2_STAMP(10 * LI + 2);
   // the level(s) below
   if constexpr (LAST) {
     const int reps = cx.direct ? 1 : cx.reps[LI];     // a direct solve repeated on the same right-hand side returns the same bits
-    for (int r = 0; r < reps; ++r) t2_solve5<T2Ctx<T, TCO, TC, SM, NCTOP, DIV>, T, TCO, NCTOP>(cx, r == 0);
+    for (int r = 0; r < reps; ++r) t2_solve5<T2Ctx<T, TCO, TC, SM, NCTOP, DIV, VAR>, T, TCO, NCTOP, VAR>(cx, r == 0);
   } else {
     constexpr int NCC = NC / 2;
     using GC = T2Geo<NCC>;
@@ -515,7 +592,7 @@ __device__ __forceinline__ void t2_visit(T2Ctx<T, TCO, TC, SM, NCTOP, DIV>& cx, 
         Fc[k][1] = (q.active && i >= 1) ? row[1] : T(0);
       }
       const int reps = cx.reps[LI];
-      for (int r = 0; r < reps; ++r) t2_visit<LI + 1, NCC, T, TCO, TC, SM, NCTOP, DIV>(cx, st, r == 0);
+      for (int r = 0; r < reps; ++r) t2_visit<LI + 1, NCC, T, TCO, TC, SM, NCTOP, DIV, VAR>(cx, st, r == 0);
       // ... and publish their iterate for the interpolation
       auto& Uc = t2_U<LI + 1>(st);
       if (q.active) {
@@ -538,11 +615,19 @@ __device__ __forceinline__ void t2_visit(T2Ctx<T, TCO, TC, SM, NCTOP, DIV>& cx, 
   // up leg: u += P e -> post sweeps
   t2_prolong_add<T, TX, TC, NC>(U, p, ec);
   T2_STAMP(10 * LI + 4);
-  t2_smooth<T, NC, SM, DIV>(U, F, cx.xbuf, cx.stage, p, c, cx.post);
+  t2_smooth<T, NC, SM, DIV, VAR>(U, F, cx.xbuf, cx.stage, p, c, cf, cx.post);
   T2_STAMP(10 * LI + 5);
 }
 
-template <typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV>
+template <typename T, int NC, int LI, typename S>
+__device__ __forceinline__ void t2_load_coefs(S& st, const Tail2Args& a) {
+  const T2Lane q = t2_lane<NC>();
+  if (!T2Geo<NC>::BLOCK && threadIdx.x >= 64) return;     // a one-wave level
+  t2_load_coef<T, NC>(t2_C<LI>(st), q, reinterpret_cast<const T*>(a.a_lv[LI]), reinterpret_cast<const T*>(a.rd_lv[LI]), a.a_ld[LI]);
+  if constexpr (NC > 8) t2_load_coefs<T, NC / 2, LI + 1>(st, a);
+}
+
+template <typename T, typename TCO, typename TC, int SM, int NCTOP, bool DIV, bool VAR>
 __global__ __launch_bounds__(T2Geo<NCTOP>::WAVES * 64) void tail2_kernel(const T* __restrict__ rhs_top, T* __restrict__ u_top,
                                                                           Tail2Args a, int zero_top, int* __restrict__ sweeps_out) {
   using G = T2Geo<NCTOP>;
@@ -550,9 +635,10 @@ __global__ __launch_bounds__(T2Geo<NCTOP>::WAVES * 64) void tail2_kernel(const T
   using P = T2Pair<T>;
   constexpr int R = G::R;
   extern __shared__ __attribute__((aligned(16))) unsigned char pool[];
-  T2Ctx<T, TCO, TC, SM, NCTOP, DIV> cx{a, pool, reinterpret_cast<T*>(pool + L::kX), 0, 0,
-                                       t2_pin((T)a.omega), t2_pin((T)(1.0 - a.omega)), t2_pin((T)a.coeff),
-                                       a.pre, a.post, a.colour_offset, a.direct, 0, {0, 0, 0, 0, 0, 0, 0, 0, 0}, {}, {}};
+  T2Ctx<T, TCO, TC, SM, NCTOP, DIV, VAR> cx{a, pool, reinterpret_cast<T*>(pool + L::kX), 0, 0,
+                                            t2_pin((T)a.omega), t2_pin((T)(1.0 - a.omega)), t2_pin((T)a.coeff),
+                                            a.pre, a.post, a.colour_offset, a.direct, 0, {0, 0, 0, 0, 0, 0, 0, 0, 0}, {}, {},
+                                            VAR ? t2_pin((T)a.sigma) : T(0)};
 #pragma unroll
   for (int l = 0; l < kT2MaxLev; ++l) {
     cx.lvc[l][0] = t2_pin((T)a.lv[l].ihx2); cx.lvc[l][1] = t2_pin((T)a.lv[l].ihy2);
@@ -564,7 +650,7 @@ __global__ __launch_bounds__(T2Geo<NCTOP>::WAVES * 64) void tail2_kernel(const T
   T2_STAMP(90);
   // the top level first: its loads are in flight while the staging arrays are zeroed
   const T2Lane p = t2_lane<NCTOP>();
-  T2State<T, NCTOP> st;
+  T2State<T, NCTOP, VAR> st;
   auto& U = t2_U<0>(st);
   auto& F = t2_F<0>(st);
   int ld = a.ld_top;
@@ -596,7 +682,12 @@ __global__ __launch_bounds__(T2Geo<NCTOP>::WAVES * 64) void tail2_kernel(const T
       TCO* sf = reinterpret_cast<TCO*>(pool + L::kFive) + 25;
       if (i == 0 || i == 4 || j == 0 || j == 4) sf[t] = reinterpret_cast<const TCO*>(a.ring5)[(size_t)i * a.ring5_ld + j];
     }
+    if (VAR && !a.direct && t < 25) {
+      TCO* sa = reinterpret_cast<TCO*>(pool + L::kFive) + 50;
+      sa[t] = reinterpret_cast<const TCO*>(a.a_lv[kT2MaxLev])[(size_t)(t / 5) * a.a_ld[kT2MaxLev] + t % 5];
+    }
   }
+  if constexpr (VAR) t2_load_coefs<T, NCTOP, 0>(st, a);
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     F[k][0] = p.ok0 ? f2[k].v[0] : T(0);            // column 0 is a boundary cell: no interior cell reads its rhs
@@ -606,7 +697,7 @@ __global__ __launch_bounds__(T2Geo<NCTOP>::WAVES * 64) void tail2_kernel(const T
   }
   __syncthreads();
   T2_STAMP(91);
-  t2_visit<0, NCTOP, T, TCO, TC, SM, NCTOP, DIV>(cx, st, zero_top != 0);
+  t2_visit<0, NCTOP, T, TCO, TC, SM, NCTOP, DIV, VAR>(cx, st, zero_top != 0);
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const int i = R * p.strip + k;

@@ -299,6 +299,17 @@ void d_inject(int di, int dout, const void* fine, void* coarse, int ldf, int nxc
   else launch_inject<float, double>(fine, coarse, ldf, nxc, nyc, ldc, stride, st);
 }
 
+template <typename T>
+void launch_rdiag(const void* a, void* rd, int nx, int ny, int ld, double hx, double hy, double sigma, hipStream_t st) {
+  const Coef c = coefs(hx, hy);
+  hipLaunchKernelGGL(mg::var_rdiag_kernel<T>, dim3(grid_for((long long)nx * ny)), dim3(mg::kBlock), 0, st, (const T*)a, (T*)rd, nx, ny, ld,
+                     (T)c.ihx2, (T)c.ihy2, (T)sigma);
+}
+void d_rdiag(int dt, const void* a, void* rd, int nx, int ny, int ld, double hx, double hy, double sigma, hipStream_t st) {
+  if (dt == MG_F32) launch_rdiag<float>(a, rd, nx, ny, ld, hx, hy, sigma, st);
+  else launch_rdiag<double>(a, rd, nx, ny, ld, hx, hy, sigma, st);
+}
+
 // ------------------------------------------------------------------ fused legs ----------------
 struct LegGeom;
 template <typename T, int HALO, int TI>
@@ -331,6 +342,7 @@ struct LegGeom {      // what every fused launch needs
   int select = 0, in_i_lo = 0, in_i_hi = 0, in_j_lo = 0, in_j_hi = 0;   // tile selection (see mg::FusedArgs)
   double sigma = 0.0;                                                    // Helmholtz shift (see coefs)
   const void* acoef = nullptr;                                           // variable coefficient: vertex values (dtype / pitch of u)
+  const void* rdiag = nullptr;                                           // ... and its reciprocal diagonal per cell (var_rdiag_kernel)
   int rb = 0;                                                            // 1: register-blocked legs on the bandwidth-bound levels
 };
 inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
@@ -358,7 +370,7 @@ void launch_down_ti(const void* u, const void* rhs, void* out, void* rhs_c, cons
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   mg::FusedArgs a = fused_args<T, HALO, TI>(g.nx, g.ny, g.ld, g.nsweep, !c.pow2, g.nxc, g.nyc, g.ldc, g.poff);
   apply_sub(a, g);
-  void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T, const T*, T);
+  void (*k)(const T*, const T*, T*, const TX*, TX*, double*, mg::FusedArgs, T, T, T, T, T, T, T, const T*, T, const T*);
   if (g.acoef) {      // variable coefficient (one symbol for all levels: TAG 0)
     k = zero_init ? mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, true, TX, T, 0, SM, TI, true>
                   : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 0, SM, TI, true>;
@@ -368,7 +380,7 @@ void launch_down_ti(const void* u, const void* rhs, void* out, void* rhs_c, cons
                   : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostRestrict, false, TX, T, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr,
                      (TX*)rhs_c, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff,
-                     (const T*)g.acoef, (T)g.sigma);
+                     (const T*)g.acoef, (T)g.sigma, (const T*)g.rdiag);
 }
 template <typename T, typename TX, int SM>
 void launch_down(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
@@ -392,7 +404,7 @@ int launch_up_ti(const void* u, const void* rhs, void* out, const void* e_c, dou
                     : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNorm, false, TX, TC, 0, SM, TI>;
     hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
                        (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff,
-                       (const T*)g.acoef, (T)g.sigma);
+                       (const T*)g.acoef, (T)g.sigma, (const T*)g.rdiag);
     return a.ntiles;
   }
   constexpr int HALO = 2 * mg::sweep_halo(SM);
@@ -403,7 +415,7 @@ int launch_up_ti(const void* u, const void* rhs, void* out, const void* e_c, dou
                   : mg::fused_jacobi_kernel<T, HALO, true, mg::kPostNone, false, TX, TC, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c,
                      (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff,
-                     (const T*)g.acoef, (T)g.sigma);
+                     (const T*)g.acoef, (T)g.sigma, (const T*)g.rdiag);
   return 0;
 }
 template <typename T, typename TX, typename TC, int SM>
@@ -425,7 +437,7 @@ void launch_sweeps_ti(const void* u, const void* rhs, void* out, const LegGeom& 
                   : mg::fused_jacobi_kernel<T, HALO, false, mg::kPostNone, false, T, T, 0, SM, TI>;
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(mg::kFusedBlock), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr,
                      (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0,
-                     (const T*)g.acoef, (T)g.sigma);
+                     (const T*)g.acoef, (T)g.sigma, (const T*)g.rdiag);
 }
 template <typename T, int SM>
 void launch_sweeps(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
@@ -456,8 +468,20 @@ inline bool rb_stream(const LegGeom& g, size_t esz) {
   return (size_t)g.nx * g.ld * esz > (size_t)100 << 20;
 }
 // kernel variant by streaming hints (TAG 2) -- VAR is a template argument of the launcher so that only the shapes in use
-// are instantiated: constant coefficients 4 waves x 8 rows, variable coefficients 8 waves x 4 rows (the same 32-row
-// region; the face means of 4 rows per lane keep the kernel at ~120 VGPRs instead of 256)
+// are instantiated: constant coefficients 4 waves x 8 rows (fp64 red-black GS, whose halo is 6 rows: 8 x 8, a 64-row
+// region of which 52 rows are tile instead of 20 of 32 -- down / up leg 95 / 98 -> 91 / 91 us at 4097^2; the other three
+// lose 3-30 % with it), variable coefficients 8 waves x 4 rows (a 32-row region; the face means of 4 rows per lane keep
+// the kernel at ~125 VGPRs instead of 256; 16 x 4 measured 192 / 194 us against 165 / 180)
+// measurement builds (-DMG_EXPERIMENTS -DMG_EXP_VAR_W=16 / -DMG_EXP_RB_W=8): other workgroup shapes of the same kernels
+#if !defined(MG_EXPERIMENTS) && (defined(MG_EXP_VAR_W) || defined(MG_EXP_RB_W))
+#error "MG_EXP_* switches need -DMG_EXPERIMENTS (a measurement build, never the shipped library)"
+#endif
+#ifndef MG_EXP_VAR_W
+#define MG_EXP_VAR_W 8
+#endif
+#ifndef MG_EXP_RB_W
+#define MG_EXP_RB_W ((SM == mg::kSmRbgs && sizeof(T) == 8) ? 8 : 4)
+#endif
 #define MG_RB_PICK(nt, ...) ((nt) ? mg::rb_leg_kernel<__VA_ARGS__, 2, SM, W, RPT, VAR> : mg::rb_leg_kernel<__VA_ARGS__, 1, SM, W, RPT, VAR>)
 template <typename T, typename TX, int SM, int W, int RPT, bool VAR>
 void launch_down_rb_s(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
@@ -469,7 +493,7 @@ void launch_down_rb_s(const void* u, const void* rhs, void* out, void* rhs_c, co
                      : MG_RB_PICK(nt, T, HALO, false, mg::kPostRestrict, false, TX, T);
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st, (const T*)u, (const T*)rhs, (T*)out, (const TX*)nullptr, (TX*)rhs_c,
                      (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff,
-                     (const T*)g.acoef, (T)g.sigma);
+                     (const T*)g.acoef, (T)g.sigma, (const T*)g.rdiag);
 }
 template <typename T, typename TX, typename TC, int SM, int W, int RPT, bool VAR>
 int launch_up_rb_s(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm, hipStream_t st) {
@@ -481,7 +505,7 @@ int launch_up_rb_s(const void* u, const void* rhs, void* out, const void* e_c, d
     auto k = MG_RB_PICK(nt, T, HALO, true, mg::kPostNorm, false, TX, TC);
     hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                        (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c, (TX*)nullptr, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
-                       (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff, (const T*)g.acoef, (T)g.sigma);
+                       (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff, (const T*)g.acoef, (T)g.sigma, (const T*)g.rdiag);
     return a.ntiles;
   }
   constexpr int HALO = 2 * mg::sweep_halo(SM);
@@ -489,7 +513,7 @@ int launch_up_rb_s(const void* u, const void* rhs, void* out, const void* e_c, d
   auto k = MG_RB_PICK(nt, T, HALO, true, mg::kPostNone, false, TX, TC);
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                      (const T*)u, (const T*)rhs, (T*)out, (const TX*)e_c, (TX*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
-                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff, (const T*)g.acoef, (T)g.sigma);
+                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff, (const T*)g.acoef, (T)g.sigma, (const T*)g.rdiag);
   return 0;
 }
 template <typename T, int SM, int W, int RPT, bool VAR>
@@ -501,22 +525,22 @@ void launch_sweeps_rb_s(const void* u, const void* rhs, void* out, const LegGeom
   auto k = MG_RB_PICK(nt, T, HALO, false, mg::kPostNone, false, T, T);
   hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st,
                      (const T*)u, (const T*)rhs, (T*)out, (const T*)nullptr, (T*)nullptr, (double*)nullptr, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD,
-                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0, (const T*)g.acoef, (T)g.sigma);
+                     (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)0, (const T*)g.acoef, (T)g.sigma, (const T*)g.rdiag);
 }
 template <typename T, typename TX, int SM>
 void launch_down_rb(const void* u, const void* rhs, void* out, void* rhs_c, const LegGeom& g, bool zero_init, hipStream_t st) {
-  if (g.acoef) launch_down_rb_s<T, TX, SM, 8, 4, true>(u, rhs, out, rhs_c, g, zero_init, st);
-  else launch_down_rb_s<T, TX, SM, 4, 8, false>(u, rhs, out, rhs_c, g, zero_init, st);
+  if (g.acoef) launch_down_rb_s<T, TX, SM, MG_EXP_VAR_W, 4, true>(u, rhs, out, rhs_c, g, zero_init, st);
+  else launch_down_rb_s<T, TX, SM, MG_EXP_RB_W, 8, false>(u, rhs, out, rhs_c, g, zero_init, st);
 }
 template <typename T, typename TX, typename TC, int SM>
 int launch_up_rb(const void* u, const void* rhs, void* out, const void* e_c, double* partials, const LegGeom& g, bool norm, hipStream_t st) {
-  return g.acoef ? launch_up_rb_s<T, TX, TC, SM, 8, 4, true>(u, rhs, out, e_c, partials, g, norm, st)
-                 : launch_up_rb_s<T, TX, TC, SM, 4, 8, false>(u, rhs, out, e_c, partials, g, norm, st);
+  return g.acoef ? launch_up_rb_s<T, TX, TC, SM, MG_EXP_VAR_W, 4, true>(u, rhs, out, e_c, partials, g, norm, st)
+                 : launch_up_rb_s<T, TX, TC, SM, MG_EXP_RB_W, 8, false>(u, rhs, out, e_c, partials, g, norm, st);
 }
 template <typename T, int SM>
 void launch_sweeps_rb(const void* u, const void* rhs, void* out, const LegGeom& g, hipStream_t st) {
-  if (g.acoef) launch_sweeps_rb_s<T, SM, 8, 4, true>(u, rhs, out, g, st);
-  else launch_sweeps_rb_s<T, SM, 4, 8, false>(u, rhs, out, g, st);
+  if (g.acoef) launch_sweeps_rb_s<T, SM, MG_EXP_VAR_W, 4, true>(u, rhs, out, g, st);
+  else launch_sweeps_rb_s<T, SM, MG_EXP_RB_W, 8, false>(u, rhs, out, g, st);
 }
 
 // One weighted-Jacobi sweep on a level above ~1100^2 cells: the register-blocked sweeps kernel with nsweep = 1 (same
@@ -663,6 +687,7 @@ void release(mg_handle* h) {
       if (l.rhs[d]) (void)hipFree(l.rhs[d]);
       if (l.r[d]) (void)hipFree(l.r[d]);
       if (l.a[d]) (void)hipFree(l.a[d]);
+      if (l.rd[d]) (void)hipFree(l.rd[d]);
     }
   if (h->d_tail_ops) (void)hipFree(h->d_tail_ops);
   if (h->partials) (void)hipFree(h->partials);
@@ -673,6 +698,15 @@ void release(mg_handle* h) {
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
   if (h->h_int) (void)hipHostFree(h->h_int);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+}
+
+// reciprocal diagonals of every level and precision, for the current coefficient and shift (variable coefficients only)
+void refresh_rdiag(mg_handle* h) {
+  if (!h->varcoef || h->rd_sigma == h->sigma) return;
+  for (auto& v : h->lv)
+    for (int dt = 0; dt < 2; ++dt)
+      if (v.a[dt] && v.rd[dt]) d_rdiag(dt, v.a[dt], v.rd[dt], v.nx, v.ny, v.ld[dt], v.hx, v.hy, h->sigma, h->stream);
+  h->rd_sigma = h->sigma;
 }
 
 // ---- the cycle -----------------------------------------------------------------------------
@@ -961,7 +995,9 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
     if (h->tail_direct && h->tail_minv_sigma != h->sigma) { const int rc = build_coarse_inverse(h); if (rc != MG_OK) return rc; }
     return tail2_launch(h, zero_u);
   }
-  if (l == h->tail_start && h->cfg.tail != 0 && (h->tail2_start < 0 || l < h->tail2_start)) return launch_tail(h, zero_u);
+  // the LDS tail only where the register-resident one does not apply (a variable-coefficient fp32 hierarchy could enter the
+  // LDS tail one level earlier, at 65^2: 107 us per launch against two 33^2 register tails and one pair of legs, ~70)
+  if (l == h->tail_start && h->cfg.tail != 0 && h->tail2_start < 0) return launch_tail(h, zero_u);
   if (l == L - 1) {
     coarse_solve(h, l, zero_u);
     return MG_OK;
@@ -973,7 +1009,7 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   LegGeom g{f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, 0, h->cfg.colour_offset, fine};
   g.sigma = h->sigma;
   g.rb = rb_mode(h);
-  if (h->varcoef) g.acoef = f.a[dt];
+  if (h->varcoef) { g.acoef = f.a[dt]; g.rdiag = f.rd[dt]; }
   if (part != kPartBack) {
     StageTimer tm(h, &f, 0);
     int extra = std::max(0, h->cfg.pre - 2);
@@ -1268,6 +1304,27 @@ bool stagnating(const std::vector<double>& hist) {
   return inc;
 }
 
+// The residual an fp32 iterate can reach: every cell's r = f - A u carries the rounding of diag(A) u, so ||r||_h settles at
+// about eps32 * diag(A) * ||u||_h (measured: 1.8 against 2.0 at 4097^2, 1.9e-3 against 1.95e-3 at 129^2) -- h^-2 times the
+// round-off of u.  Within a factor 2 of it another fp32 cycle cannot lower the residual: the policy promotes at once
+// instead of waiting for the five-norm stagnation window (core/precision.py:189-246) to fill with a flat history.
+bool at_fp32_floor(const mg_handle* h, double rn) { return h->fp32_floor > 0.0 && rn <= 2.0 * h->fp32_floor; }
+
+// Before the first cycle the same floor can be bounded from above: ||u|| <= ||f|| / lambda_min with lambda_min =
+// |coeff| pi^2 (1/Lx^2 + 1/Ly^2) + sigma of the Dirichlet problem, so floor / ||r_0|| <= eps32 diag(A) / lambda_min -- a number
+// that depends on the grid only (1.2e-8 / h^2 on the unit square: 0.2 at 4097^2, 0.013 at 1025^2).  Cycles contract ||r|| by
+// ~0.15, so the fp32 phase is good for log(that) / log(0.15) cycles; entering and leaving it costs about one cycle's saving
+// (two ring conversions, the ||u|| pass, the cast of the iterate, no speculative front part across either switch): the policy
+// takes the fp32 phase only when it is good for at least two cycles, and stays in double otherwise -- an adaptive solve then
+// never loses to a double one.
+bool fp32_phase_pays(const mg_handle* h) {
+  const Level& v = h->lv[0];
+  const double lx = h->cfg.x1 - h->cfg.x0, ly = h->cfg.y1 - h->cfg.y0, pi = 3.14159265358979323846;
+  const double lam = std::fabs(h->cfg.coeff) * pi * pi * (1.0 / (lx * lx) + 1.0 / (ly * ly)) + h->sigma;
+  const double ratio = 5.9604644775390625e-8 * coefs(v.hx, v.hy, h->sigma).diag / lam;
+  return ratio > 0.0 && std::log(ratio) / std::log(0.15) >= 2.0;
+}
+
 // core/precision.py:270-302 update_precision (+ the one-way variant documented in mghip.h): the precision the coming
 // cycle runs in.  Pure -- `*promote` says whether taking the decision also ends the adaptive phase for good.
 int adapt_target(const mg_handle* h, double rn, bool* promote) {
@@ -1283,8 +1340,8 @@ int adapt_target(const mg_handle* h, double rn, bool* promote) {
     if (mem_down || (h->phase == MG_F64 && rn > thr * 100)) { if (h->phase == MG_F64) to = MG_F32; }
     else if (h->phase == MG_F32 && rn < thr * 10) to = MG_F64;
   } else if (!h->promoted) {
-    if (h->phase == MG_F64 && (mem_down || rn > thr * 100) && h->adapt_hist.empty()) to = MG_F32;
-    else if (h->phase == MG_F32 && (rn < thr * 10 || stagnating(h->adapt_hist))) { to = MG_F64; *promote = true; }
+    if (h->phase == MG_F64 && (mem_down || (rn > thr * 100 && fp32_phase_pays(h))) && h->adapt_hist.empty()) to = MG_F32;
+    else if (h->phase == MG_F32 && (rn < thr * 10 || stagnating(h->adapt_hist) || at_fp32_floor(h, rn))) { to = MG_F64; *promote = true; }
   }
   return to;
 }
@@ -1292,7 +1349,13 @@ int adapt_target(const mg_handle* h, double rn, bool* promote) {
 int adapt(mg_handle* h, double rn, bool iterate_is_zero = false) {
   bool promote = false;
   const int to = adapt_target(h, rn, &promote);
-  if (promote) h->promoted = true;
+  if (promote) {
+    h->promoted = true;
+    h->switch_reason = rn < h->cfg.switch_threshold * 10 ? 1 : (stagnating(h->adapt_hist) ? 2 : 3);
+  } else if (h->cfg.precision == MG_PREC_ADAPTIVE && !h->cfg.adaptive_reference_rule && !h->promoted && h->phase == MG_F64 &&
+             to == MG_F64 && h->adapt_hist.empty() && rn > h->cfg.switch_threshold * 100) {
+    h->switch_reason = 4;                                  // the fp32 phase was declined a priori (fp32_phase_pays)
+  }
   return switch_phase(h, to, iterate_is_zero);
 }
 
@@ -1608,12 +1671,15 @@ int mg_set_coefficient(mg_handle* h, const void* a_host, int host_dtype) {
     for (int dt = 0; dt < 2; ++dt) {
       if (!v.u[dt]) continue;
       if (!v.a[dt]) { const int rc = alloc_zero(&h->err, &v.a[dt], (size_t)v.nx * v.ld[dt] * esize(dt), h->stream); if (rc != MG_OK) return rc; }
+      if (!v.rd[dt]) { const int rc = alloc_zero(&h->err, &v.rd[dt], (size_t)v.nx * v.ld[dt] * esize(dt), h->stream); if (rc != MG_OK) return rc; }
       d_inject(host_dtype, dt, h->staging, v.a[dt], lds, v.nx, v.ny, v.ld[dt], 1 << l, h->stream);
     }
   }
-  HIPC(&h->err, hipStreamSynchronize(h->stream));
   const bool was = h->varcoef;
   h->varcoef = true;
+  h->rd_sigma = -1.0;                                      // new coefficient: new reciprocal diagonals
+  refresh_rdiag(h);
+  HIPC(&h->err, hipStreamSynchronize(h->stream));
   h->tail_minv_sigma = -1.0;                               // a direct coarsest solve needs the inverse of the NEW operator
   return was ? MG_OK : plan_tail(h);                       // the LDS tail carries one more array per level
 }
@@ -1630,6 +1696,8 @@ int mg_set_shift(mg_handle* h, double sigma) {
     return fail(h ? &h->err : nullptr, MG_ERR_INVALID_VALUE, "mg_set_shift: sigma must be finite and >= 0");
   h->sigma = sigma;
   h->norm_partials = 0;     // a cached sum r^2 belongs to the previous operator
+  HIPC(&h->err, hipSetDevice(h->cfg.device));
+  refresh_rdiag(h);         // variable coefficients: the reciprocal diagonals carry the shift
   return MG_OK;
 }
 
@@ -1693,6 +1761,8 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
     h->promoted = false;
     h->adapt_hist.clear();
   }
+  h->fp32_floor = 0.0;
+  h->switch_reason = 0;
   for (auto& l : h->lv) l.timings[0] = l.timings[1] = l.timings[2] = 0;
   const double t0 = now_s();
   double rn = 0;
@@ -1779,6 +1849,10 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
       }
       // ... nor across the end of the solve: the norm in flight, extrapolated the same way, meets the tolerance
       if (it >= 2 && prev_rn > 0 && rn * std::min(1.0, rn / prev_rn) < tol) switch_likely = true;
+      // ... nor before the fp32 residual floor of this solve is known (floor_due): it is evaluated from the iterate this
+      // cycle leaves, right after its norm, and usually ends the fp32 phase there
+      if (h->cfg.precision == MG_PREC_ADAPTIVE && h->phase == MG_F32 && !h->promoted && !h->cfg.adaptive_reference_rule &&
+          h->fp32_floor == 0.0) switch_likely = true;
       if (it < max_iter && !switch_likely) {
         if ((rc = cycle_fused(h, 0, false, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
         spec = true;
@@ -1795,6 +1869,18 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
       if ((rc = fine_norm(h, &rn)) != MG_OK) return rc;         // multigrid.py:233
     }
     h->adapt_hist.push_back(rn);
+    if (h->cfg.precision == MG_PREC_ADAPTIVE && h->phase == MG_F32 && !h->promoted && !h->cfg.adaptive_reference_rule &&
+        h->fp32_floor == 0.0 && !spec) {
+      // once per solve, after the first fp32 cycle (no front part of the next cycle is queued yet: see `floor_due` above):
+      // ||u||_h of the fp32 iterate -> the residual this precision can reach (at_fp32_floor)
+      Level& v0 = h->lv[0];
+      const int np = d_sumsq(MG_F32, v0.u[MG_F32], h->partials, v0.ld[MG_F32], 0, v0.nx, 0, v0.ny, h->stream);
+      double su = 0;
+      if ((rc = reduce_to_host(h, np, &su)) != MG_OK) return rc;
+      h->norm_partials = 0;                     // `partials` no longer holds this cycle's sum of r^2
+      const Coef c0 = coefs(v0.hx, v0.hy, h->sigma);
+      h->fp32_floor = 5.9604644775390625e-8 * c0.diag * std::sqrt(v0.hx * v0.hy * su);      // eps32 = 2^-24
+    }
     if (it <= hist_cap) hist[it - 1] = rn;
     if (prec_hist && it <= hist_cap)
       prec_hist[it - 1] = (h->cfg.precision == MG_PREC_MIXED_LEVELS) ? 2 : h->level_dtype(0);
@@ -1807,6 +1893,8 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
   st->last_coarse_sweeps = *h->h_int;
   st->solve_seconds = now_s() - t0;
   st->precision_switches = switches;
+  st->switch_reason = h->switch_reason;
+  st->fp32_floor = h->fp32_floor;
   if (n_iter) *n_iter = it;
   if (converged) *converged = conv;
   return MG_OK;
@@ -1909,14 +1997,14 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
                   if (d_prolong<true>(dc, dt, h->grid_dtype, c.u[dc], v.u[dt], v.nx, v.ny, v.ld[dt], c.ld[dc], h->stream) != MG_OK) return MG_ERR_INVALID_VALUE; } break;
         case 6: { const int rc = run_cycle(h); if (rc != MG_OK) return rc; } break;
         case 7: { Level& c = h->lv[level + 1]; const int dc = c.rhs[dt] ? dt : 1 - dt;          // down leg
-                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) g.acoef = v.a[dt];
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) { g.acoef = v.a[dt]; g.rdiag = v.rd[dt]; }
                   d_down(h->cfg.smoother, dt, dc, v.u[dt], v.rhs[dt], v.t[dt], c.rhs[dc], g, false, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         case 8: { Level& c = h->lv[level + 1]; const int dc = c.u[dt] ? dt : 1 - dt;            // up leg (+ norm on level 0)
-                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) g.acoef = v.a[dt];
+                  LegGeom g{v.nx, v.ny, v.ld[dt], c.nx, c.ny, c.ld[dc], v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) { g.acoef = v.a[dt]; g.rdiag = v.rd[dt]; }
                   if (d_up(h->cfg.smoother, dt, dc, h->grid_dtype, v.u[dt], v.rhs[dt], v.t[dt], c.u[dc], h->partials, g, level == 0, h->stream) < 0) return MG_ERR_INVALID_VALUE;
                   std::swap(v.u[dt], v.t[dt]); } break;
-        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) g.acoef = v.a[dt];
+        case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) { g.acoef = v.a[dt]; g.rdiag = v.rd[dt]; }
                   d_sweeps(h->cfg.smoother, dt, v.u[dt], v.rhs[dt], v.t[dt], g, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         default: return MG_ERR_INVALID_VALUE;
@@ -2026,22 +2114,22 @@ int mg_dev_down_leg(int smoother, int dtype, int coarse_dtype, int nx, int ny, i
                     int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
                     const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream, int select, const int* inner_rect) {
   return mg_dev_down_leg_var(smoother, dtype, coarse_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off, cj_off, hx, hy, omega, coeff, nsweep,
-                             zero_init, colour_offset, u, rhs, out, rhs_coarse, stream, select, inner_rect, nullptr);
+                             zero_init, colour_offset, u, rhs, out, rhs_coarse, stream, select, inner_rect, nullptr, nullptr);
 }
 
 int mg_dev_down_leg_var(int smoother, int dtype, int coarse_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc, int ci_off,
                         int cj_off, double hx, double hy, double omega, double coeff, int nsweep, int zero_init, int colour_offset,
                         const void* u, const void* rhs, void* out, void* rhs_coarse, void* stream, int select, const int* inner_rect,
-                        const void* acoef) {
+                        const void* acoef, const void* rdiag) {
   CHECK_DEV((smoother == MG_JACOBI || smoother == MG_RBGS) && valid_dtype(dtype) && valid_dtype(coarse_dtype), "mg_dev_down_leg: bad smoother / dtype");
-  CHECK_DEV(!acoef || aligned16(acoef), "mg_dev_down_leg: bad coefficient pointer");
+  CHECK_DEV((!acoef && !rdiag) || (acoef && rdiag && aligned16(acoef) && aligned16(rdiag)), "mg_dev_down_leg: coefficient and reciprocal diagonal come together, 16-byte aligned");
   CHECK_DEV(nx >= 3 && ny >= 3 && nxc >= 3 && nyc >= 3 && ld_ok(dtype, ny, ld) && ldc >= nyc && nsweep >= 0 && nsweep <= 2, "mg_dev_down_leg: bad shape / pitch / sweep count");
   CHECK_DEV(rhs && out && rhs_coarse && (zero_init || u) && u != out && aligned16(rhs) && aligned16(out) && (!u || aligned16(u)), "mg_dev_down_leg: bad pointer");
   LegGeom g{nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, colour_offset, false};
   g.ci_off = ci_off; g.cj_off = cj_off;
   CHECK_DEV(select >= 0 && select <= 2 && (select == 0 || inner_rect), "mg_dev_down_leg: bad tile selection");
   if (select) { g.select = select; g.in_i_lo = inner_rect[0]; g.in_i_hi = inner_rect[1]; g.in_j_lo = inner_rect[2]; g.in_j_hi = inner_rect[3]; }
-  g.acoef = acoef;
+  g.acoef = acoef; g.rdiag = rdiag;
   g.rb = 1;                       // register-blocked legs on blocks above ~1100^2 cells (same results, mg_config.fused = 2)
   d_down(smoother, dtype, coarse_dtype, u ? u : rhs, rhs, out, rhs_coarse, g, zero_init != 0, (hipStream_t)stream);
   HIPC(nullptr, hipGetLastError());
@@ -2054,25 +2142,33 @@ int mg_dev_up_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, 
                   int nj_hi, void* scratch, double* sumsq_dev, void* stream) {
   return mg_dev_up_leg_var(smoother, dtype, coarse_dtype, compute_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off, cj_off, sides, hx, hy, omega,
                            coeff, nsweep, colour_offset, u, rhs, out, e_coarse, norm, ni_lo, ni_hi, nj_lo, nj_hi, scratch, sumsq_dev,
-                           stream, nullptr);
+                           stream, nullptr, nullptr);
 }
 
 int mg_dev_up_leg_var(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
                       int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
                       const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
-                      int nj_hi, void* scratch, double* sumsq_dev, void* stream, const void* acoef) {
+                      int nj_hi, void* scratch, double* sumsq_dev, void* stream, const void* acoef, const void* rdiag) {
   CHECK_DEV((smoother == MG_JACOBI || smoother == MG_RBGS) && valid_dtype(dtype) && valid_dtype(coarse_dtype) && valid_dtype(compute_dtype), "mg_dev_up_leg: bad smoother / dtype");
-  CHECK_DEV(!acoef || aligned16(acoef), "mg_dev_up_leg: bad coefficient pointer");
+  CHECK_DEV((!acoef && !rdiag) || (acoef && rdiag && aligned16(acoef) && aligned16(rdiag)), "mg_dev_up_leg: coefficient and reciprocal diagonal come together, 16-byte aligned");
   CHECK_DEV(nx >= 3 && ny >= 3 && nxc >= 2 && nyc >= 2 && ld_ok(dtype, ny, ld) && ldc >= nyc && nsweep >= 0 && nsweep <= 2 && sides >= 0 && sides <= 15, "mg_dev_up_leg: bad shape / pitch / sweep count");
   CHECK_DEV(u && rhs && out && e_coarse && u != out && aligned16(u) && aligned16(rhs) && aligned16(out) && (!norm || (scratch && sumsq_dev)), "mg_dev_up_leg: bad pointer");
   LegGeom g{nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep, colour_offset, false};
   g.ci_off = ci_off; g.cj_off = cj_off; g.sides = sides;
   if (norm) { g.ni_lo = ni_lo; g.ni_hi = ni_hi; g.nj_lo = nj_lo; g.nj_hi = nj_hi; }
-  g.acoef = acoef;
+  g.acoef = acoef; g.rdiag = rdiag;
   g.rb = 1;
   const int n = d_up(smoother, dtype, coarse_dtype, compute_dtype, u, rhs, out, e_coarse, (double*)scratch, g, norm != 0, (hipStream_t)stream);
   if (n < 0) return fail(nullptr, MG_ERR_INVALID_VALUE, "mg_dev_up_leg: fp32 interpolation needs fp32 coarse and fine fields");
   if (norm) launch_reduce((double*)scratch, n, sumsq_dev, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
+int mg_dev_var_rdiag(int dtype, int nx, int ny, int ld, double hx, double hy, double sigma, const void* a, void* rdiag, void* stream) {
+  CHECK_DEV(valid_dtype(dtype) && nx >= 3 && ny >= 3 && ld_ok(dtype, ny, ld) && sigma >= 0.0, "mg_dev_var_rdiag: bad shape / pitch / shift");
+  CHECK_DEV(a && rdiag && a != rdiag, "mg_dev_var_rdiag: bad pointer");
+  d_rdiag(dtype, a, rdiag, nx, ny, ld, hx, hy, sigma, (hipStream_t)stream);
   HIPC(nullptr, hipGetLastError());
   return MG_OK;
 }

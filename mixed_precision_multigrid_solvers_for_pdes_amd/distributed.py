@@ -207,24 +207,30 @@ class HipOps:
     supports_overlap = True
     plan_capable = True               # cycles can be recorded into a native plan (dist_plan.py)
 
+    def var_rdiag(self, a, rd, lnx, lny, hx, hy, sigma=0.0):
+        """reciprocal diagonal of -div(a grad .) on this array (mg_dev_var_rdiag): what the variable-coefficient sweeps multiply by"""
+        _lib.check(self.lib.mg_dev_var_rdiag(self._code(a), lnx, lny, a.stride(0), hx, hy, float(sigma), self._p(a), self._p(rd), self._stream()))
+
     def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff,
-                 select=0, inner=None, acoef=None):
+                 select=0, inner=None, acoef=None, rdiag=None):
         """select: 0 all tiles; 1 only tiles that need nothing outside `inner` = (i_lo, i_hi, j_lo, j_hi); 2 the others.
-        acoef: vertex values of the diffusion coefficient on this array (None: constant-coefficient operator)."""
+        acoef / rdiag: vertex values of the diffusion coefficient on this array and its reciprocal diagonal (var_rdiag);
+        None: constant-coefficient operator."""
         rect = (C.c_int * 4)(*inner) if inner is not None else None
         _lib.check(self.lib.mg_dev_down_leg_var(sm, self._code(rhs), self._code(rhs_c), lnx, lny, rhs.stride(0), lnxc, lnyc,
                                                 rhs_c.stride(0), ci_off, cj_off, hx, hy, omega, coeff, nsweep, int(zero_init), poff,
                                                 None if zero_init else self._p(u), self._p(rhs), self._p(out), self._p(rhs_c),
-                                                self._stream(), int(select), rect, None if acoef is None else self._p(acoef)))
+                                                self._stream(), int(select), rect, None if acoef is None else self._p(acoef),
+                                                None if rdiag is None else self._p(rdiag)))
         if self.rec is not None:
             clamp = lambda v: max(-(1 << 30), min(1 << 30, int(v)))
             self.rec.emit(_lib.MG_PLAN_DOWN_LEG,
                           i=(sm, self._code(rhs), self._code(rhs_c), lnx, lny, rhs.stride(0), lnxc, lnyc, rhs_c.stride(0), ci_off, cj_off,
                              nsweep, int(zero_init), poff, int(select), int(inner is not None)) + tuple(clamp(v) for v in (inner or (0, 0, 0, 0))),
-                          d=(hx, hy, omega, coeff), p=(None if zero_init else u, rhs, out, rhs_c, acoef))
+                          d=(hx, hy, omega, coeff), p=(None if zero_init else u, rhs, out, rhs_c, acoef, rdiag))
 
     def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff,
-               window=None, acoef=None):
+               window=None, acoef=None, rdiag=None):
         """out = sweeps(u + P e_c); with `window` = (i_lo, i_hi, j_lo, j_hi) also returns sum r^2 over it (device tensor)."""
         w = window or (0, 0, 0, 0)
         res = self.torch.empty(1, dtype=self.torch.float64, device=self.device) if window is not None else self.acc
@@ -233,12 +239,12 @@ class HipOps:
                                               e_c.stride(0), ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, self._p(u),
                                               self._p(rhs), self._p(out), self._p(e_c), int(window is not None), w[0], w[1], w[2],
                                               w[3], self._p(self.scratch), self._p(res), self._stream(),
-                                              None if acoef is None else self._p(acoef)))
+                                              None if acoef is None else self._p(acoef), None if rdiag is None else self._p(rdiag)))
         if self.rec is not None:
             self.rec.emit(_lib.MG_PLAN_UP_LEG,
                           i=(sm, self._code(u), self._code(e_c), self.comp_dt, lnx, lny, u.stride(0), lnxc, lnyc, e_c.stride(0), ci_off,
                              cj_off, sides, nsweep, poff, int(window is not None)) + tuple(w),
-                          d=(hx, hy, omega, coeff), p=(u, rhs, out, e_c, self.scratch, res, acoef))
+                          d=(hx, hy, omega, coeff), p=(u, rhs, out, e_c, self.scratch, res, acoef, rdiag))
         return res if window is not None else None
 
     def inject_ring(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides, ci_off, cj_off):
@@ -399,7 +405,7 @@ class DistributedMultigrid:
             d = _Dom()
             d.rank, d.rx, d.ry = r, rx, ry
             d.blk = [Block(a, b, px, py, rx, ry, self.G) for (a, b) in self.shapes[:self.Ld + 1]]
-            d.u, d.t, d.rhs, d.r, d.a = [], [], [], [], []
+            d.u, d.t, d.rhs, d.r, d.a, d.rd = [], [], [], [], [], []
             for l in range(self.Ld):
                 b = d.blk[l]
                 d.u.append(ops.alloc(b.lnx, b.lny, self.ldt[l]))
@@ -407,6 +413,7 @@ class DistributedMultigrid:
                 d.rhs.append(ops.alloc(b.lnx, b.lny, self.ldt[l]))
                 d.r.append(ops.alloc(b.lnx, b.lny, self.ldt[l]) if self.mode == "per_operator" else None)
                 d.a.append(None)
+                d.rd.append(None)
             # the agglomeration level: a local coarse buffer (restriction target / prolongation source)
             if self.Ld > 0:
                 b = d.blk[self.Ld]
@@ -716,7 +723,8 @@ class DistributedMultigrid:
 
     # ---- native replay (dist_plan.py) --------------------------------------------------------------
     def _pointer_state(self):
-        return tuple((d.u[l].data_ptr(), d.t[l].data_ptr(), d.rhs[l].data_ptr(), 0 if d.a[l] is None else d.a[l].data_ptr())
+        return tuple((d.u[l].data_ptr(), d.t[l].data_ptr(), d.rhs[l].data_ptr(), 0 if d.a[l] is None else d.a[l].data_ptr(),
+                      0 if d.rd[l] is None else d.rd[l].data_ptr())
                      for d in self.doms.values() for l in range(self.Ld)) + \
             tuple(0 if d.ring_sumsq is None else d.ring_sumsq.data_ptr() for d in self.doms.values()) + (self.var,)
 
@@ -827,7 +835,7 @@ class DistributedMultigrid:
                 b, bc = d.blk[l], d.blk[l + 1]
                 ci, cj = b.coarse_offsets(bc)
                 target = d.rc if last else d.rhs[l + 1]
-                kw = {"acoef": d.a[l]} if self.var else {}
+                kw = {"acoef": d.a[l], "rdiag": d.rd[l]} if self.var else {}
                 with self._ph("legs"):
                     self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l], target, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, hx, hy,
                                       self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1,
@@ -881,7 +889,7 @@ class DistributedMultigrid:
             ci, cj = b.coarse_offsets(bc)
             e = d.ec if last else d.u[l + 1]
             win = (max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), max(b.j_lo, 1), min(b.j_hi, b.lny - 1)) if want_norm else None
-            kw = {"acoef": d.a[l]} if self.var else {}
+            kw = {"acoef": d.a[l], "rdiag": d.rd[l]} if self.var else {}
             with self._ph("legs"):
                 res = self.ops.up_leg(self.smk, d.u[l], d.rhs[l], d.t[l], e, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides, hx, hy,
                                       self.omega, self.coeff, self.post, (b.gx0 + b.gy0) & 1, win, **kw)
@@ -942,7 +950,10 @@ class DistributedMultigrid:
                 vals = np.asarray(a_at((b.gx0 + np.arange(b.lnx)) << l, (b.gy0 + np.arange(b.lny)) << l))
                 if d.a[l] is None:
                     d.a[l] = self.ops.alloc(b.lnx, b.lny, self.ldt[l])
+                    d.rd[l] = self.ops.alloc(b.lnx, b.lny, self.ldt[l])
                 d.a[l][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(vals, dtype=self.ldt[l])).to(d.a[l].device)
+                # the reciprocal diagonal of the block (ghost zone included: it only needs the block's own coefficient values)
+                self.ops.var_rdiag(d.a[l], d.rd[l], b.lnx, b.lny, self.h[l][0], self.h[l][1])
         NXa, NYa = self.shapes[self.Ld]
         self.ops.coarse_coefficient(np.ascontiguousarray(a_at(np.arange(NXa) << self.Ld, np.arange(NYa) << self.Ld), dtype=np.float64))
         self.var = True
@@ -1012,7 +1023,7 @@ class DistributedMultigrid:
                     d.zc = self.ops.alloc(bc.lnx, bc.lny, self.ldt[1])
                 win = (max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), max(b.j_lo, 1), min(b.j_hi, b.lny - 1))
                 res = self.ops.up_leg(self.smk, d.u[0], d.rhs[0], d.t[0], d.zc, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides, hx, hy,
-                                      self.omega, self.coeff, 0, (b.gx0 + b.gy0) & 1, win, acoef=d.a[0])
+                                      self.omega, self.coeff, 0, (b.gx0 + b.gy0) & 1, win, acoef=d.a[0], rdiag=d.rd[0])
                 d.t[0].copy_(d.u[0])
                 parts[r] = res + d.ring_sumsq
             return math.sqrt(hx * hy * self.allreduce_sum(parts))
@@ -1024,6 +1035,20 @@ class DistributedMultigrid:
             if d.r[0] is None:                       # t doubled as scratch: restore its boundary ring / contents
                 tmp.copy_(d.u[0])
         return math.sqrt(hx * hy * self.allreduce_sum(parts))
+
+    def iterate_sumsq(self):
+        """sum of u^2 over the whole grid (every rank its exclusive window), as a Python float on every rank"""
+        self._settle()
+        parts = {}
+        for r, d in self.doms.items():
+            b = d.blk[0]
+            parts[r] = self.ops.sumsq(d.u[0], b.i_lo, b.i_hi, b.j_lo, b.j_hi)
+        total = None
+        for r in self.ranks:
+            total = parts[r] if total is None else total + parts[r]
+        if self.dist is not None:
+            self.dist.all_reduce(total)
+        return float(total.item())
 
     def take_iterate_from(self, other):
         """The fine iterate of `other` (same decomposition, another working precision) becomes this solver's iterate:
@@ -1079,22 +1104,50 @@ def stagnating(hist):
     return all(r[i] >= r[i - 1] * 0.99 for i in range(1, 5))
 
 
+def fp32_phase_pays(hx, hy, domain, coeff=-1.0, sigma=0.0):
+    """csrc/mghip.hip fp32_phase_pays: the fp32 residual floor relative to ||r_0|| is at most eps32 diag(A) / lambda_min (a
+    property of the grid); with a contraction of ~0.15 per cycle the fp32 phase is good for log(that) / log(0.15) cycles, and
+    it is entered only when that is at least two -- its switches cost about one cycle's saving."""
+    lx, ly = domain[1] - domain[0], domain[3] - domain[2]
+    lam = abs(coeff) * math.pi**2 * (1.0 / (lx * lx) + 1.0 / (ly * ly)) + sigma
+    ratio = 2.0**-24 * (2.0 / (hx * hx) + 2.0 / (hy * hy) + sigma) / lam
+    return ratio > 0.0 and math.log(ratio) / math.log(0.15) >= 2.0
+
+
 class AdaptivePolicy:
     """The engine's adaptive rule (csrc/mghip.hip: adapt, one-way variant of core/precision.py:270-302) as host logic
     for drivers that hold one solver per precision: start in double, drop to single on a large first residual,
     promote for good when ||r|| < 10 thr or the fp32 iteration stagnates."""
 
-    def __init__(self, thr):
+    EPS32 = 2.0 ** -24
+
+    def __init__(self, thr, fp32_pays=True):
+        """fp32_pays: the fp32 phase is good for at least two cycles on this grid (fp32_phase_pays); False: stay in double"""
         self.thr, self.phase, self.promoted, self.hist = thr, "f64", False, []
+        self.fp32_pays = bool(fp32_pays)
+        self.floor = 0.0          # eps32 * diag(A) * ||u||_h: the residual an fp32 iterate can reach (set_floor; 0: not evaluated)
+        self.reason = None        # why the fp32 phase ended: "threshold" / "stagnation" / "fp32_floor"; "fp32_skipped": never begun
+
+    def set_floor(self, diag, u_norm_h):
+        """after the first fp32 cycle (csrc/mghip.hip, iterate_impl): within a factor 2 of this floor another fp32 cycle
+        cannot lower the residual, and the policy promotes at once instead of waiting for the stagnation window to fill"""
+        self.floor = self.EPS32 * diag * u_norm_h
+
+    def floor_due(self):
+        return self.phase == "f32" and not self.promoted and self.floor == 0.0
 
     def before_cycle(self, rn):
         """-> the precision the coming cycle runs in (the caller moves the iterate when it differs from .phase)"""
         want = self.phase
         if not self.promoted:
             if self.phase == "f64" and rn > 100.0 * self.thr and not self.hist:
-                want = "f32"
-            elif self.phase == "f32" and (rn < 10.0 * self.thr or stagnating(self.hist)):
+                if self.fp32_pays:
+                    want = "f32"
+                else:
+                    self.reason = "fp32_skipped"
+            elif self.phase == "f32" and (rn < 10.0 * self.thr or stagnating(self.hist) or 0.0 < self.floor and rn <= 2.0 * self.floor):
                 want, self.promoted = "f64", True
+                self.reason = "threshold" if rn < 10.0 * self.thr else ("stagnation" if stagnating(self.hist) else "fp32_floor")
         if want != self.phase:
             self.phase = want
             self.hist = []
@@ -1106,6 +1159,8 @@ class AdaptivePolicy:
     def switch_likely(self):
         """Will the norm of the cycle about to run change the precision?  Extrapolated from the last two norms of this
         phase, as the engine does before it queues a speculative front part (csrc/mghip.hip, iterate_impl)."""
+        if self.floor_due():
+            return True                # the floor is evaluated from the iterate the coming cycle leaves and usually ends the phase
         if self.promoted or self.phase != "f32" or len(self.hist) < 2:
             return False
         prev, last = self.hist[-2], self.hist[-1]
@@ -1151,7 +1206,10 @@ class DecomposedSolve:
         self.switches = 0
 
     def _new_policy(self):
-        return AdaptivePolicy(self.thr) if self.policy_kind == "adaptive" else FixedPolicy(self.start)
+        if self.policy_kind != "adaptive":
+            return FixedPolicy(self.start)
+        sv = self.solvers[self.start]
+        return AdaptivePolicy(self.thr, fp32_phase_pays(sv.h[0][0], sv.h[0][1], sv.domain, sv.coeff))
 
     def set_problem(self, rhs_of_block, u0_of_block=None):
         """every precision takes the right-hand side (and the initial guess); a solve starts in `start` (double when there
@@ -1186,6 +1244,9 @@ class DecomposedSolve:
         sv.cycle(0)
         self.rn = sv.residual_norm()
         policy.after_cycle(self.rn)
+        if getattr(policy, "floor_due", None) is not None and policy.floor_due():
+            hx, hy = sv.h[0]
+            policy.set_floor(2.0 / (hx * hx) + 2.0 / (hy * hy), math.sqrt(hx * hy * sv.iterate_sumsq()))
         return self.rn
 
     def run(self, tol, max_iterations):

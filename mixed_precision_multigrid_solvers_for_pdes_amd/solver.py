@@ -43,8 +43,16 @@ def _precision_config(grid, pm):
 class MultigridSolver(BaseSolver):
     def __init__(self, max_levels=4, max_iterations=50, tolerance=1e-8, cycle_type=MultigridCycle.V_CYCLE,
                  pre_smooth_iterations=2, post_smooth_iterations=2, coarse_tolerance=1e-12,
-                 coarse_max_iterations=1000, verbose=False, device_id=0, profile=False, fmg_cycles=0):
+                 coarse_max_iterations=1000, verbose=False, device_id=0, profile=False, fmg_cycles=0, coarse_direct=None):
+        """coarse_direct (ours): how a 5 x 5 coarsest grid is solved.  False: the reference's lexicographic Gauss-Seidel
+        iteration to `coarse_tolerance` (solvers/multigrid.py:119-124, 355-370), bit for bit.  True: its nine unknowns
+        directly.  None (default): directly in W- / F-cycles -- they visit the coarsest grid 2^(L-1) times per cycle and
+        spend most of their time in that iteration -- and by the iteration in V-cycles.  A direct solve satisfies
+        coarse_tolerance exactly; residual histories then agree with the reference's to max(1e-9 relative,
+        coarse_tolerance absolute) -- the accuracy the reference's own coarse solver is configured for -- and iterates to
+        1e-12 relative (tests/test_gpu_solver.py)."""
         super().__init__(max_iterations, tolerance, verbose, "Multigrid")
+        self.coarse_direct = coarse_direct
         self.max_levels = max_levels
         self.cycle_type = cycle_type
         self.pre_smooth_iterations = pre_smooth_iterations
@@ -130,7 +138,7 @@ class MultigridSolver(BaseSolver):
                 g.nx, g.ny, g.domain, self._setup_args[1], self.max_levels, self.cycle_type,
                 self.pre_smooth_iterations, self.post_smooth_iterations, self.smoother.kind, self.smoother.omega,
                 self.coarse_tolerance, self.coarse_max_iterations, prec, thr, mem, ref_rule,
-                self.device_id, self.profile, fmg_cycles=self.fmg_cycles)
+                self.device_id, self.profile, fmg_cycles=self.fmg_cycles, coarse_direct=self.coarse_direct)
             if self._coefficient_field is not None:
                 self._engines[key].set_coefficient(self._coefficient_field)
         return self._engines[key]
@@ -188,7 +196,10 @@ class MultigridSolver(BaseSolver):
             info.update({"initial_residual": last["initial_residual"], "device_id": self.device_id,
                          "gpu_solve_time": last["solve_seconds"],
                          "gpu_transfer_time": last["h2d_seconds"] + last["d2h_seconds"],
-                         "kernel_time": last["solve_seconds"]})
+                         "kernel_time": last["solve_seconds"],
+                         # adaptive policy: why the fp32 phase ended ("threshold" / "stagnation" / "fp32_floor"), or
+                         # "fp32_skipped" when it was declined a priori (include/mghip.h, mg_stats)
+                         "switch_reason": last.get("switch_reason"), "fp32_floor": last.get("fp32_floor", 0.0)})
         return info
 
     def cleanup(self):

@@ -425,6 +425,10 @@ def defect_correction(mgo, rhs, u0=None, tol=1e-8, max_iterations=50):
 # checked by (i) a == 1 reproducing the constant-coefficient functions above bit for bit on dyadic grids and
 # (ii) second-order convergence on a manufactured solution.
 #   face values: arithmetic means of the vertex values; coarse operators: a injected (re-discretisation).
+#   Round 3: the smoothers MULTIPLY by the reciprocal diagonal, un = (f + nb) * (1 / D) with 1 / D rounded once in the level's
+#   dtype, instead of dividing by D -- the diagonal depends on the coefficient only, so the device keeps 1 / D as one more field
+#   per level and its sweeps have no division left (they were division-bound).  For a == 1 on dyadic grids 1 / D is exact and
+#   nothing changes; elsewhere results move by an ulp (this operator is ours to define: there is no reference to keep).
 # --------------------------------------------------------------------------
 
 def _faces(a):
@@ -449,7 +453,7 @@ def _var_update(u, f, a, hx, hy, omega, shift=0.0):
     sx = aip * u[2:, 1:-1] + aim * u[:-2, 1:-1]
     sy = ajp * u[1:-1, 2:] + ajm * u[1:-1, :-2]
     D = (aip + aim) * ihx2 + (ajp + ajm) * ihy2 + shift
-    un = (f[1:-1, 1:-1] + (ihx2 * sx + ihy2 * sy)) / D
+    un = (f[1:-1, 1:-1] + (ihx2 * sx + ihy2 * sy)) * (1.0 / D)
     return (1.0 - omega) * u[1:-1, 1:-1] + omega * un
 
 
@@ -481,7 +485,7 @@ def var_lexgs_sweep(u, f, a, hx, hy, shift=0.0):
         ajp, ajm = 0.5 * (a[i, j] + a[i, j + 1]), 0.5 * (a[i, j] + a[i, j - 1])
         nb = (aip * u[i + 1, j] + aim * u[i - 1, j]) / hx2 + (ajp * u[i, j + 1] + ajm * u[i, j - 1]) / hy2
         D = (aip + aim) / hx2 + (ajp + ajm) / hy2 + shift
-        u[i, j] = (1 - 1.0) * u[i, j] + 1.0 * ((f[i, j] + nb) / D)
+        u[i, j] = (1 - 1.0) * u[i, j] + 1.0 * ((f[i, j] + nb) * (1.0 / D))
     return u
 
 

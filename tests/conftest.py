@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The engine's default solves the 5 x 5 coarsest grid of W- / F-cycles directly (MultigridEngine(coarse_direct=None) ->
+# "auto"): within 1e-12 of the reference's iterates, not bit-identical.  The suite's many bit-for-bit comparisons between
+# engine paths (fused legs vs one launch per operator, decomposed vs single domain, kernels vs oracle) are statements about
+# the reference-faithful iteration, so the suite pins it; tests of the default pass coarse_direct="auto" explicitly.
+os.environ.setdefault("MG_COARSE_DIRECT", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

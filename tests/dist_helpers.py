@@ -134,8 +134,11 @@ class NumpyOps:
                 inner[m] = upd[m]
         return v
 
+    def var_rdiag(self, a, rd, lnx, lny, hx, hy, sigma=0.0):
+        pass                      # the oracle's smoothers form 1 / D themselves (oracle/mg_oracle.py: _var_update)
+
     def down_leg(self, sm, u, rhs, out, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep, zero_init, poff,
-                 select=0, inner=None, acoef=None):
+                 select=0, inner=None, acoef=None, rdiag=None):
         assert select == 0          # no streams on the CPU: the driver never splits the launch here
         f = self._v(rhs, lnx, lny)
         a = None if acoef is None else self._v(acoef, lnx, lny)
@@ -153,7 +156,7 @@ class NumpyOps:
         c[np.ix_(ic[oki], jc[okj])] = (1.0 / 16.0 * corners + 1.0 / 8.0 * edges) + 1.0 / 4.0 * r[I, J]
 
     def up_leg(self, sm, u, rhs, out, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep, poff, window=None,
-               acoef=None):
+               acoef=None, rdiag=None):
         f = self._v(rhs, lnx, lny)
         a = None if acoef is None else self._v(acoef, lnx, lny)
         v = self._v(u, lnx, lny).copy()

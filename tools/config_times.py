@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cycle times of the BASELINE configurations that fit one GPU (device-resident, mg_iterate, tol = 0).
 
-    python3 tools/config_times.py [all|const|var]
+    python3 tools/config_times.py [all|const|var] [substring of the row's name]
 """
 import os
 import sys
@@ -29,7 +29,10 @@ VAR = [("config 5 as specified on one GPU: 16385^2 -div(a grad u) mixed W(2,2) r
        ("4097^2 -div(a grad u) fp64 W(2,2) red-black GS", 4097, "W", _lib.MG_RBGS, 1.0, _lib.MG_PREC_DOUBLE, 5)]
 only = sys.argv[1] if len(sys.argv) > 1 else "all"
 cases = [c + (False,) for c in CASES if only in ("all", "const")] + [c + (True,) for c in VAR if only in ("all", "var")]
+pick = sys.argv[2] if len(sys.argv) > 2 else ""
 for name, n, cyc, sm, omega, prec, its, var in cases:
+    if pick not in name:
+        continue
     x = np.linspace(0, 1, n)
     rhs = 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(np.pi * x)[None, :]
     eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), cycle=cyc, smoother=sm, omega=omega, precision=prec,
