@@ -92,8 +92,13 @@ typedef struct mg_config {
                                 arithmetic per cell in all three */
   int32_t fmg_cycles;        /* > 0: mg_solve without an initial guess starts from a full-multigrid guess with this many
                                 cycles per level (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:583-652) */
-  int32_t speculate;         /* with fused = 1 -- 1: mg_iterate / mg_solve queue the down leg of cycle k+1 while ||r_k||
-                                travels to the host (dropped if that norm ends the solve); 0: strictly one cycle at a time */
+  int32_t speculate;         /* with fused -- 1: mg_iterate / mg_solve queue the down leg of cycle k+1 while ||r_k|| travels to
+                                the host (dropped if that norm ends the solve); 2 (the host side's default): as 1, and where the
+                                finest level is bandwidth-bound (> ~1100^2 cells, Jacobi, constant coefficients) the up leg of
+                                cycle k and that down leg are ONE launch (the spanning leg, csrc/mg_rb_kernels.hpp): the iterate
+                                between the two cycles is written (unless tol <= 0 and no precision switch is pending: nothing
+                                can end the solve there) but never read back.  Same iterates bit for bit; the norm's partial
+                                sums are taken over other tiles (last-bit differences).  0: strictly one cycle at a time */
   int32_t coarse_direct;     /* 1 (with fused and tail, a 5 x 5 coarsest grid): the nine-unknown coarsest system is solved
                                 directly (u = A^-1 f, the inverse formed on the host) instead of by the reference's Gauss-Seidel
                                 iteration to coarse_tol (solvers/multigrid.py:119-124, 355-370).  NOT bit-identical to the

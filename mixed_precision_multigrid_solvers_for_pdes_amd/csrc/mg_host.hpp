@@ -57,6 +57,7 @@ struct Level {
   int ld[2] = {0, 0};
   void* u[2] = {nullptr, nullptr};     // current iterate
   void* t[2] = {nullptr, nullptr};     // Jacobi ping-pong partner (same boundary ring as u)
+  void* s[2] = {nullptr, nullptr};     // level 0, allocated on first use: third buffer of the spanning leg (cycle_span)
   void* rhs[2] = {nullptr, nullptr};
   void* r[2] = {nullptr, nullptr};     // residual
   void* a[2] = {nullptr, nullptr};     // diffusion coefficient (variable-coefficient operator), else null
@@ -106,6 +107,7 @@ struct mg_handle {
   double zero_norm_val[2] = {0, 0};
   int norm_partials = 0;           // > 0: `partials` holds sum r^2 over interior cells of the CURRENT fine iterate
   int tail_start = -1;             // first level of the single-workgroup LDS tail (-1: none)
+  bool span_ring[2] = {false, false};   // the third level-0 buffer (Level::s) carries the Dirichlet ring of this solve
   int tail2_start = -1;            // first level of the register-resident tail (mg_tail.hip; -1: none); it takes precedence
   int tail2_ntop = 0;              // points per side of that level (65, 33 or 17)
   int* d_tail_ops = nullptr;       // device copy of the tail schedule

@@ -147,14 +147,20 @@ __device__ __forceinline__ void rb_exchange(Pack<T>* __restrict__ xb, int w, int
 // VAR: the variable-coefficient operator (varcoef_kernel's discretisation and association order): the strip of `a` is
 // loaded with u and rhs, its edge rows go through the exchange once, and the face means of the lane's cells --
 // (RPT + 1) x N vertical, RPT x (N + 1) horizontal -- live in registers for the whole leg.
+// SPAN (with PROLONG and POST == kPostRestrict): the up leg of cycle k and the down leg of cycle k + 1 in ONE pass over the
+// strip -- u += P e, a.nsweep post sweeps, [the iterate of cycle k -> `out` (SPAN 1; SPAN 2 skips the store: the caller
+// knows the solve cannot end at k)], sum r_k^2 of the tile -> partials, a.nsweep2 pre sweeps of cycle k + 1 -> `out2`,
+// residual, full weighting.  The iterate between the two cycles is never read back: 4.75 (3.75) words per cell instead of
+// 6.5.  HALO counts both sweep sets.
 template <typename T, int HALO, bool PROLONG, int POST, bool ZERO_INIT, typename TX, typename TC, int SM, int W, int RPT, bool INT, int NT,
-          bool VAR>
+          bool VAR, int SPAN = 0>
 __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out,
                                             const TX* __restrict__ e_coarse, TX* __restrict__ rhs_coarse,
                                             double* __restrict__ partials, const FusedArgs& a, T ihx2, T ihy2, T invD, T D, T omega,
                                             T one_m_omega, T coeff, Pack<T>* __restrict__ xbuf, TX* __restrict__ patch,
                                             double* __restrict__ red, int i0, int j0, const T* __restrict__ acoef, T sigma,
-                                            const T* __restrict__ rdiag) {
+                                            const T* __restrict__ rdiag, T* __restrict__ out2 = nullptr) {
+  static_assert(SPAN == 0 || (PROLONG && POST == kPostRestrict && !ZERO_INIT), "a spanning leg is an up leg followed by a down leg");
   using S = RbShape<T, HALO, W, RPT>;
   constexpr int N = S::N;
   constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
@@ -264,7 +270,8 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
 
   // ---- sweeps ------------------------------------------------------------------------------------------------------
   int stage = 0;
-  const int npass = (SM == kSmRbgs) ? 2 * a.nsweep : a.nsweep;
+  auto run_sweeps = [&](int nsw) {
+  const int npass = (SM == kSmRbgs) ? 2 * nsw : nsw;
   for (int s = 0; s < npass; ++s, ++stage) {
     Pack<T> above, below;
     rb_exchange<T, W>(xbuf + (size_t)(stage & 1) * W * 2 * 64, w, lane, U[0], U[RPT - 1], above, below);
@@ -320,22 +327,29 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
     if (SM == kSmRbgs && ((par0 + colour) & 1) != 0) pass(std::integral_constant<int, 1>{});
     else pass(std::integral_constant<int, 0>{});
   }
+  };
+  run_sweeps(a.nsweep);
 
   // ---- write the tile of u' ------------------------------------------------------------------------------------------
   const bool lane_in_tile = lane >= S::HL && lane < 64 - S::HL;
+  auto store_tile = [&](T* __restrict__ dst) {
 #pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    const int r = r_base + k, gi = ri0 + r;
-    if (r >= HALO && r < HALO + S::TI && lane_in_tile && (INT || (gi < a.nx && gj0 < a.nyv))) {
-      if (NT & 1) stg_nt(out + (size_t)gi * a.ld + gj0, U[k]); else stg(out + (size_t)gi * a.ld + gj0, U[k]);
+    for (int k = 0; k < RPT; ++k) {
+      const int r = r_base + k, gi = ri0 + r;
+      if (r >= HALO && r < HALO + S::TI && lane_in_tile && (INT || (gi < a.nx && gj0 < a.nyv))) {
+        if (NT & 1) stg_nt(dst + (size_t)gi * a.ld + gj0, U[k]); else stg(dst + (size_t)gi * a.ld + gj0, U[k]);
+      }
     }
-  }
+  };
+  if (SPAN != 2) store_tile(out);
   if (POST == kPostNone) return;
 
   // ---- residual of the strip (r = f on boundary cells, as f is 0 outside the grid so is r) ------------------------------
   Pack<T> R[RPT];
   double acc = 0.0;
-  {
+  // NORM (compile time): the residual of the tile only, its squares summed into acc; else of the whole strip (restriction)
+  auto residual = [&](auto norm_stage) {
+    constexpr bool NORM = decltype(norm_stage)::value;
     Pack<T> above, below;
     rb_exchange<T, W>(xbuf + (size_t)(stage & 1) * W * 2 * 64, w, lane, U[0], U[RPT - 1], above, below);
     ++stage;
@@ -349,7 +363,7 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
       const T right = dpp_from_upper_lane<T>(mid.v[0]);
       Pack<T> o = F[k];
       const bool in_tile = r >= HALO && r < HALO + S::TI && lane_in_tile;
-      const bool wanted = (POST == kPostRestrict) || in_tile;        // the norm only needs r on the tile itself
+      const bool wanted = !NORM || in_tile;                          // the norm only needs r on the tile itself
       const bool row_ok = INT ? ((k > 0 || w > 0) && (k < RPT - 1 || w < W - 1))
                               : (r >= 1 && r < S::RI - 1 && gi >= 1 && gi < a.nx - 1);
       if (wanted && row_ok && !VAR) {
@@ -359,7 +373,7 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
           const int gj = gj0 + e;
           if (INT || (gj >= 1 && gj < a.ny - 1)) {
             o.v[e] = rr.v[e];
-            if (POST == kPostNorm && in_tile && (INT || (gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi)))
+            if (NORM && in_tile && (INT || (gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi)))
               acc += (double)o.v[e] * (double)o.v[e];
           }
         }
@@ -382,19 +396,25 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
           const int gj = gj0 + e;
           if (INT || (gj >= 1 && gj < a.ny - 1)) {
             o.v[e] = F[k].v[e] - au;
-            if (POST == kPostNorm && in_tile && (INT || (gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi)))
+            if (NORM && in_tile && (INT || (gi >= a.ni_lo && gi < a.ni_hi && gj >= a.nj_lo && gj < a.nj_hi)))
               acc += (double)o.v[e] * (double)o.v[e];
           }
         }
       }
       R[k] = o;
     }
-  }
-  if (POST == kPostNorm) {
+  };
+  if (POST == kPostNorm || SPAN) {
+    residual(std::true_type{});
     const double t = block_reduce_sum<W>(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
-    return;
+    if (!SPAN) return;
   }
+  if (SPAN) {                       // cycle k + 1 begins: pre sweeps, the iterate the next up leg will read, then residual + restriction
+    run_sweeps(a.nsweep2);
+    store_tile(out2);
+  }
+  residual(std::false_type{});
 
   // ---- full weighting of the interior coarse cells that sit on this tile (operators/transfer.py:100-124) -------------
   {
@@ -483,6 +503,49 @@ __global__ __launch_bounds__(W * 64, (VAR && sizeof(T) == 8) ? 4 : 1) void rb_le
     rb_leg_body<T, HALO, PROLONG, POST, ZERO_INIT, TX, TC, SM, W, RPT, false, kNT, VAR>(u, rhs, out, e_coarse, rhs_coarse, partials, a, ihx2, ihy2,
                                                                                  invD, D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0,
                                                                                  acoef, sigma, rdiag);
+}
+
+// The spanning leg of the finest level (rb_leg_body, SPAN): up leg of cycle k + down leg of cycle k + 1.  `out_mid`: the
+// iterate of cycle k (SPAN 1), `out_next`: the pre-smoothed iterate of cycle k + 1, `partials`: sum r_k^2 per workgroup.
+// Whole grids only (no tile selection, no sub-array offsets beyond FusedArgs').
+// Four waves per SIMD (<= 128 registers): two 8-wave workgroups per CU.  Left alone half of the variants take 129-139 and
+// run one (the fp64 leg without the store in between: 171 us against 145 with it).
+template <typename T, int HALO, typename TX, typename TC, int TAG, int SM, int W, int RPT, int SPAN>
+__global__ __launch_bounds__(W * 64, 4) void rb_span_kernel(
+    const T* __restrict__ u, const T* __restrict__ rhs, T* __restrict__ out_mid, T* __restrict__ out_next,
+    const TX* __restrict__ e_coarse, TX* __restrict__ rhs_coarse, double* __restrict__ partials,
+    FusedArgs a, T ihx2, T ihy2, T invD, T D, T omega, T one_m_omega, T coeff) {
+  using S = RbShape<T, HALO, W, RPT>;
+  constexpr int N = S::N;
+  constexpr int kNT = (TAG == 2) ? MG_RB_NT_MODE : 0;
+  constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
+  constexpr size_t kXBytes = (size_t)2 * W * 2 * 64 * sizeof(Pack<T>);
+  constexpr size_t kPatchBytes = (size_t)PH * PW * sizeof(TX);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kXBytes + kPatchBytes];
+  __shared__ double red[W];
+  Pack<T>* const xbuf = reinterpret_cast<Pack<T>*>(lds);
+  TX* const patch = reinterpret_cast<TX*>(lds + kXBytes);
+
+  const int L = xcd_remap(blockIdx.x, a.ntiles);
+  const int ti = L / a.tiles_j, tj = L - ti * a.tiles_j;
+  const int i0 = 1 + ti * S::TI, j0 = tj * S::TJ;
+  const int ri0 = i0 - HALO, rj0 = j0 - S::HL * N;
+  bool interior = ri0 >= 1 && ri0 + S::RI <= a.nx - 1 && rj0 >= 1 && rj0 + S::RJ <= a.ny - 1;
+  {
+    const int pic0 = (ri0 >> 1) + a.ci_off, pjc0 = (rj0 >> 1) + a.cj_off;
+    interior = interior && pic0 >= 0 && pic0 + PH <= a.nxc && pjc0 >= 0 && pjc0 + PW <= a.nyc;
+  }
+  interior = interior && i0 >= a.ni_lo && i0 + S::TI <= a.ni_hi && j0 >= a.nj_lo && j0 + S::TJ <= a.nj_hi;
+  interior = interior && ((i0 + 1) >> 1) + a.ci_off >= 1 && ((i0 + S::TI - 1) >> 1) + a.ci_off <= a.nxc - 2 &&
+             (j0 >> 1) + a.cj_off >= 1 && ((j0 + S::TJ - 2) >> 1) + a.cj_off <= a.nyc - 2;
+  if (interior)
+    rb_leg_body<T, HALO, true, kPostRestrict, false, TX, TC, SM, W, RPT, true, kNT, false, SPAN>(
+        u, rhs, out_mid, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD, D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0,
+        nullptr, T(0), nullptr, out_next);
+  else
+    rb_leg_body<T, HALO, true, kPostRestrict, false, TX, TC, SM, W, RPT, false, kNT, false, SPAN>(
+        u, rhs, out_mid, e_coarse, rhs_coarse, partials, a, ihx2, ihy2, invD, D, omega, one_m_omega, coeff, xbuf, patch, red, i0, j0,
+        nullptr, T(0), nullptr, out_next);
 }
 
 }  // namespace mg

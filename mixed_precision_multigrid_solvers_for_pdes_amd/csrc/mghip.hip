@@ -543,6 +543,33 @@ void launch_sweeps_rb(const void* u, const void* rhs, void* out, const LegGeom& 
   else launch_sweeps_rb_s<T, SM, MG_EXP_RB_W, 8, false>(u, rhs, out, g, st);
 }
 
+// Spanning leg (rb_span_kernel): 8 waves x 8 rows -- the halo of two sweep sets + residual + restriction is 6 rows
+// (Jacobi), 52 of the region's 64 rows are tile.  Returns the number of norm partials.
+template <typename T, typename TX, typename TC, int SM>
+int launch_span_rb(const void* u, const void* rhs, void* out_mid, void* out_next, const void* e_c, void* rhs_c, double* partials,
+                   const LegGeom& g, int nsweep_pre, hipStream_t st) {
+  constexpr int W = 8, RPT = 8;
+  constexpr int HALO = 4 * mg::sweep_halo(SM) + 2;
+  const Coef c = coefs(g.hx, g.hy, g.sigma);
+  mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
+  a.nsweep2 = nsweep_pre;
+  const bool nt = rb_stream(g, sizeof(T));
+  auto k = out_mid ? (nt ? mg::rb_span_kernel<T, HALO, TX, TC, 2, SM, W, RPT, 1> : mg::rb_span_kernel<T, HALO, TX, TC, 1, SM, W, RPT, 1>)
+                   : (nt ? mg::rb_span_kernel<T, HALO, TX, TC, 2, SM, W, RPT, 2> : mg::rb_span_kernel<T, HALO, TX, TC, 1, SM, W, RPT, 2>);
+  hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(W * 64), 0, st, (const T*)u, (const T*)rhs, (T*)out_mid, (T*)out_next, (const TX*)e_c,
+                     (TX*)rhs_c, partials, a, (T)c.ihx2, (T)c.ihy2, (T)c.invD, (T)c.diag, (T)g.omega, (T)(1.0 - g.omega), (T)g.coeff);
+  return a.ntiles;
+}
+// dt: dtype of the level and of the level below, dcomp: interpolation dtype.  -1: no spanning leg for this combination.
+int d_span(int dt, int dcomp, const void* u, const void* rhs, void* out_mid, void* out_next, const void* e_c, void* rhs_c,
+           double* partials, const LegGeom& g, int nsweep_pre, hipStream_t st) {
+  constexpr int SM = mg::kSmJacobi;
+  if (dt == MG_F64 && dcomp == MG_F64) return launch_span_rb<double, double, double, SM>(u, rhs, out_mid, out_next, e_c, rhs_c, partials, g, nsweep_pre, st);
+  if (dt == MG_F32 && dcomp == MG_F64) return launch_span_rb<float, float, double, SM>(u, rhs, out_mid, out_next, e_c, rhs_c, partials, g, nsweep_pre, st);
+  if (dt == MG_F32 && dcomp == MG_F32) return launch_span_rb<float, float, float, SM>(u, rhs, out_mid, out_next, e_c, rhs_c, partials, g, nsweep_pre, st);
+  return -1;
+}
+
 // One weighted-Jacobi sweep on a level above ~1100^2 cells: the register-blocked sweeps kernel with nsweep = 1 (same
 // arithmetic, same ping-pong contract as jacobi_kernel: interior rows written, the ring of `out` already equals u's).
 // MG_JACOBI_RB=0 keeps the LDS-tiled jacobi_kernel (A/B runs).
@@ -684,6 +711,7 @@ void release(mg_handle* h) {
     for (int d = 0; d < 2; ++d) {
       if (l.u[d]) (void)hipFree(l.u[d]);
       if (l.t[d]) (void)hipFree(l.t[d]);
+      if (l.s[d]) (void)hipFree(l.s[d]);
       if (l.rhs[d]) (void)hipFree(l.rhs[d]);
       if (l.r[d]) (void)hipFree(l.r[d]);
       if (l.a[d]) (void)hipFree(l.a[d]);
@@ -1050,6 +1078,60 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
   return MG_OK;
 }
 
+// Spanning leg: the BACK part of the running cycle (level-0 up leg) and the FRONT part of the next one (level-0 down leg,
+// then everything below) with ONE level-0 launch in place of two.  Buffers: u holds the pre-smoothed iterate of the running
+// cycle; the kernel writes the iterate of that cycle to t (keep_mid; dropped when the caller knows the solve cannot end
+// there) and the pre-smoothed iterate of the next cycle to the third buffer s.  Afterwards u = s (what the next up leg
+// reads), t = the iterate (undo_front's swap brings it back), s = the buffer just consumed.
+bool span_ok(const mg_handle* h) {
+  if (h->cfg.speculate < 2 || !h->fused() || h->L() < 3 || h->varcoef || h->cfg.smoother != MG_JACOBI) return false;
+  if (h->cfg.pre < 1 || h->cfg.pre > 2 || h->cfg.post < 1 || h->cfg.post > 2 || h->cfg.precision == MG_PREC_DEFECT) return false;
+  const Level& f = h->lv[0];
+  LegGeom g{f.nx, f.ny, 0, 0, 0, 0, f.hx, f.hy, 0, 0, 0, 0, true};
+  g.rb = rb_mode(h);
+  if (!use_rb(g, mg::kSmJacobi)) return false;                       // bandwidth-bound levels only
+  return h->level_dtype(0) == h->level_dtype(1) && (h->level_dtype(0) == MG_F32 || h->grid_dtype == MG_F64);
+}
+int cycle_span(mg_handle* h, bool keep_mid) {
+  const int L = h->L();
+  Level& f = h->lv[0];
+  Level& c = h->lv[1];
+  const int dt = h->level_dtype(0), dc = h->level_dtype(1);
+  if (!f.s[dt]) {
+    const int rc = alloc_zero(&h->err, &f.s[dt], (size_t)f.nx * f.ld[dt] * esize(dt), h->stream);
+    if (rc != MG_OK) return rc;
+    h->span_ring[dt] = false;
+  }
+  if (!h->span_ring[dt]) {                                           // the Dirichlet ring, once per solve and working precision
+    d_convert_ring(dt, dt, f.u[dt], f.s[dt], f.nx, f.ny, f.ld[dt], f.ld[dt], h->stream);
+    h->span_ring[dt] = true;
+  }
+  LegGeom g{f.nx, f.ny, f.ld[dt], c.nx, c.ny, c.ld[dc], f.hx, f.hy, h->cfg.omega, h->cfg.coeff, 0, h->cfg.colour_offset, true};
+  g.sigma = h->sigma;
+  g.rb = rb_mode(h);
+  g.nsweep = h->cfg.post;
+  const int n = d_span(dt, h->grid_dtype, f.u[dt], f.rhs[dt], keep_mid ? f.t[dt] : nullptr, f.s[dt], c.u[dc], c.rhs[dc], h->partials, g,
+                       h->cfg.pre, h->stream);
+  if (n < 0) return MG_ERR_INVALID_VALUE;
+  void* consumed = f.u[dt];
+  f.u[dt] = f.s[dt];
+  f.s[dt] = consumed;
+  h->norm_partials = n;
+  return MG_OK;
+}
+// ... and the rest of that front part: the sub-cycle(s) below level 0 (queued after the norm reduction of the cycle before)
+int cycle_below_fine(mg_handle* h) {
+  const int L = h->L();
+  int reps = 1;
+  if (h->cfg.cycle == MG_CYCLE_W) reps = 2;
+  else if (h->cfg.cycle == MG_CYCLE_F) reps = std::max(1, 1 << std::max(0, L - 2));
+  for (int k = 0; k < reps; ++k) {
+    const int rc = cycle_fused(h, 1, k == 0);
+    if (rc != MG_OK) return rc;
+  }
+  return MG_OK;
+}
+
 // Full-multigrid initial guess (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:603-652): restrict the rhs to
 // every level (full weighting), solve the coarsest level from zero, then walk up: u_l = P u_{l+1}, followed by
 // `ncyc` cycles of the sub-hierarchy that starts at level l.  The boundary ring of the fine iterate (Dirichlet data)
@@ -1355,6 +1437,7 @@ int adapt(mg_handle* h, double rn, bool iterate_is_zero = false) {
   } else if (h->cfg.precision == MG_PREC_ADAPTIVE && !h->cfg.adaptive_reference_rule && !h->promoted && h->phase == MG_F64 &&
              to == MG_F64 && h->adapt_hist.empty() && rn > h->cfg.switch_threshold * 100) {
     h->switch_reason = 4;                                  // the fp32 phase was declined a priori (fp32_phase_pays)
+    h->promoted = true;                                    // ... for good: the rest of the solve is a double solve
   }
   return switch_phase(h, to, iterate_is_zero);
 }
@@ -1763,6 +1846,7 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
   }
   h->fp32_floor = 0.0;
   h->switch_reason = 0;
+  h->span_ring[0] = h->span_ring[1] = false;
   for (auto& l : h->lv) l.timings[0] = l.timings[1] = l.timings[2] = 0;
   const double t0 = now_s();
   double rn = 0;
@@ -1833,8 +1917,6 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
       h->norm_partials = 0;
       if (!spec && (rc = cycle_fused(h, 0, zero_first && it == 1, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
       spec = false;
-      if ((rc = cycle_fused(h, 0, false, kPartBack)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
-      const unsigned long long seq = reduce_post(h, h->norm_partials);
       // A queued front part is wasted work when the norm in flight switches the working precision (its level-0 leg runs
       // in the old one): extrapolate the norm in flight from the last two of the fp32 phase and do not speculate across a
       // switch the policy would take on it (threshold reached, or the stagnation window filling up with a flat history).
@@ -1853,9 +1935,25 @@ static int iterate_impl(mg_handle* h, double tol, int max_iter, double* hist, in
       // cycle leaves, right after its norm, and usually ends the fp32 phase there
       if (h->cfg.precision == MG_PREC_ADAPTIVE && h->phase == MG_F32 && !h->promoted && !h->cfg.adaptive_reference_rule &&
           h->fp32_floor == 0.0) switch_likely = true;
-      if (it < max_iter && !switch_likely) {
-        if ((rc = cycle_fused(h, 0, false, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+      const bool go = it < max_iter && !switch_likely;                 // queue the front part of cycle it + 1 behind this cycle
+      unsigned long long seq;
+      if (go && span_ok(h)) {
+        // up leg of this cycle and down leg of the next in one level-0 launch (cycle_span).  The iterate of THIS cycle is
+        // stored unless nothing can end the solve or change the precision on its norm: no tolerance to meet (tol <= 0, a
+        // fixed number of cycles) and no adaptive switch pending
+        const bool may_switch = h->cfg.precision == MG_PREC_ADAPTIVE && (!h->promoted || h->cfg.adaptive_reference_rule);
+        const bool keep_mid = tol > 0 || may_switch;
+        if ((rc = cycle_span(h, keep_mid)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+        seq = reduce_post(h, h->norm_partials);
+        if ((rc = cycle_below_fine(h)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
         spec = true;
+      } else {
+        if ((rc = cycle_fused(h, 0, false, kPartBack)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+        seq = reduce_post(h, h->norm_partials);
+        if (go) {
+          if ((rc = cycle_fused(h, 0, false, kPartFront)) != MG_OK) return fail(&h->err, rc, "cycle: unsupported precision combination");
+          spec = true;
+        }
       }
       HIPC(&h->err, hipGetLastError());
       double ss = 0;
@@ -1956,7 +2054,7 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
   if ((op == 2 || op == 4 || op == 5 || op == 7 || op == 8) && (level >= h->L() - 1 || !v.r[dt])) return fail(&h->err, MG_ERR_STATE, "mg_time_op: no coarser level");
   static const int exp_nsweep = exp_env("MG_EXP_NSWEEP", 2);
   h->norm_partials = 0;
-  if (level == 0 && (op == 0 || op == 1 || (op >= 5 && op <= 9))) h->iterate_zero = false;    // these rewrite the fine iterate
+  if (level == 0 && (op == 0 || op == 1 || (op >= 5 && op <= 9) || op == 12 || op == 13)) h->iterate_zero = false;    // these rewrite the fine iterate
   // op 10: the single-sweep Jacobi kernel rotating over independent {u, rhs, out} sets whose total exceeds three
   // times the 256 MiB Infinity Cache, so that no launch finds its operands on die: the HBM-proper smoother figure
   std::vector<void*> hbm_sets;
@@ -2007,6 +2105,9 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
         case 9: { LegGeom g{v.nx, v.ny, v.ld[dt], 0, 0, 0, v.hx, v.hy, h->cfg.omega, h->cfg.coeff, exp_nsweep, h->cfg.colour_offset, level == 0}; g.sigma = h->sigma; g.rb = rb_mode(h); if (h->varcoef) { g.acoef = v.a[dt]; g.rdiag = v.rd[dt]; }
                   d_sweeps(h->cfg.smoother, dt, v.u[dt], v.rhs[dt], v.t[dt], g, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
+        case 12: case 13: {                                                                      // spanning leg, with / without the store of the iterate in between
+                  if (level != 0 || !span_ok(h) || h->level_dtype(0) != dt) return MG_ERR_INVALID_VALUE;
+                  const int rc2 = cycle_span(h, op == 12); if (rc2 != MG_OK) return rc2; } break;
         default: return MG_ERR_INVALID_VALUE;
       }
     }

@@ -44,7 +44,7 @@ class MultigridEngine:
                             float(coeff), int(max_levels), int(cycle), int(pre), int(post), int(smoother),
                             float(omega), float(coarse_tol), int(coarse_maxit), int(precision),
                             float(switch_threshold), float(memory_threshold_gb), int(bool(adaptive_reference_rule)),
-                            int(device), int(bool(profile)), int(colour_offset), int(fused), int(tail), int(fmg_cycles), int(bool(speculate)),
+                            int(device), int(bool(profile)), int(colour_offset), int(fused), int(tail), int(fmg_cycles), (2 if speculate is True else int(speculate)),
                             _direct_code(coarse_direct), int(mixed_split))
         self.cfg = cfg
         self._h = C.c_void_p(None)
@@ -178,7 +178,7 @@ class MultigridEngine:
 
     def time_op(self, op, level=0, dtype=np.float64, reps=20):
         ops = {"jacobi": 0, "rbgs": 1, "residual": 2, "residual_norm": 3, "restrict": 4, "prolong": 5, "cycle": 6,
-               "down_leg": 7, "up_leg": 8, "sweeps2": 9, "jacobi_hbm": 10, "stream_hbm": 11}
+               "down_leg": 7, "up_leg": 8, "sweeps2": 9, "jacobi_hbm": 10, "stream_hbm": 11, "span_leg": 12, "span_leg_nomid": 13}
         out = C.c_double(0.0)
         self._check(self._lib.mg_time_op(self._h, ops[op] if isinstance(op, str) else int(op), int(level),
                                          _lib.dtype_code(dtype), int(reps), C.byref(out)))

@@ -1,0 +1,75 @@
+"""The spanning leg of the finest level (mg_config.speculate = 2, csrc/mg_rb_kernels.hpp rb_span_kernel): up leg of cycle k
+and down leg of cycle k + 1 in one launch.  Against the two-launch form (speculate = 1) the iterates are the same bits; the
+norm's partial sums run over other tiles, so histories agree to the last bits only."""
+import numpy as np
+import pytest
+
+import mixed_precision_multigrid_solvers_for_pdes_amd as mg
+from mixed_precision_multigrid_solvers_for_pdes_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _rhs(n):
+    x = np.linspace(0.0, 1.0, n)
+    rng = np.random.default_rng(n)
+    return 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(2 * np.pi * x)[None, :] + 0.05 * rng.standard_normal((n, n))
+
+
+def _run(n, prec, speculate, tol, its, pre=2, post=2, u0=None):
+    eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), cycle="V", smoother=_lib.MG_JACOBI, omega=0.8,
+                             precision=prec, pre=pre, post=post, speculate=speculate)
+    f = _rhs(n)
+    if prec == _lib.MG_PREC_SINGLE:
+        f = f.astype(np.float32)
+    eng.set_rhs(f)
+    eng.set_solution(u0)
+    r = eng.iterate(tol, its)
+    u = eng.get_solution()
+    eng.close()
+    return u, r
+
+
+@pytest.mark.parametrize("prec", [_lib.MG_PREC_DOUBLE, _lib.MG_PREC_SINGLE, _lib.MG_PREC_SINGLE_MANAGED, _lib.MG_PREC_ADAPTIVE])
+@pytest.mark.parametrize("n", [1281, 2049])
+def test_fixed_cycles_span_equals_two_launch_form(n, prec):
+    """tol = 0: no cycle can end the solve, the iterate between two cycles is not even stored (SPAN 2)"""
+    u1, r1 = _run(n, prec, 1, 0.0, 5)
+    u2, r2 = _run(n, prec, 2, 0.0, 5)
+    assert np.array_equal(u1, u2)
+    np.testing.assert_allclose(r2["residual_history"], r1["residual_history"], rtol=1e-12)
+    assert r1["precision_codes"] == r2["precision_codes"]
+
+
+@pytest.mark.parametrize("prec", [_lib.MG_PREC_DOUBLE, _lib.MG_PREC_SINGLE_MANAGED, _lib.MG_PREC_ADAPTIVE])
+@pytest.mark.parametrize("pre,post", [(2, 2), (1, 2), (2, 1)])
+def test_stopping_on_the_tolerance_returns_the_iterate_of_that_cycle(prec, pre, post):
+    """tol > 0: the solve ends on the norm of some cycle k while the front part of k + 1 is queued -- the iterate returned
+    is the one the spanning leg stored in between (SPAN 1), bit for bit the two-launch solve's"""
+    n = 1281
+    _, probe = _run(n, prec, 1, 0.0, 6, pre, post)
+    tol = 1.5 * probe["residual_history"][3]                  # met by the norm of the fourth cycle at the latest
+    u1, r1 = _run(n, prec, 1, tol, 12, pre, post)
+    u2, r2 = _run(n, prec, 2, tol, 12, pre, post)
+    assert r1["converged"] and r2["converged"] and 2 <= r1["iterations"] == r2["iterations"] <= 4
+    assert np.array_equal(u1, u2)
+    np.testing.assert_allclose(r2["residual_history"], r1["residual_history"], rtol=1e-12)
+
+
+def test_span_with_an_initial_guess_and_the_boundary_ring():
+    """a non-zero Dirichlet ring must survive in all three level-0 buffers"""
+    n = 1281
+    x = np.linspace(0.0, 1.0, n)
+    u0 = np.zeros((n, n))
+    u0[0, :] = np.sin(3 * x); u0[-1, :] = np.cos(2 * x); u0[:, 0] = u0[0, 0] + x * (u0[-1, 0] - u0[0, 0]); u0[:, -1] = u0[0, -1] + x * (u0[-1, -1] - u0[0, -1])
+    u1, r1 = _run(n, _lib.MG_PREC_DOUBLE, 1, 0.0, 4, u0=u0)
+    u2, r2 = _run(n, _lib.MG_PREC_DOUBLE, 2, 0.0, 4, u0=u0)
+    assert np.array_equal(u1, u2)
+    assert np.array_equal(u2[0, :], u0[0, :]) and np.array_equal(u2[:, -1], u0[:, -1])
+    # ... and a second solve on the same handle with another ring
+    eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), smoother=_lib.MG_JACOBI, omega=0.8, speculate=2)
+    eng.set_rhs(_rhs(n)); eng.set_solution(u0); eng.iterate(0.0, 3)
+    eng.set_solution(2.0 * u0); ra = eng.iterate(0.0, 3); ua = eng.get_solution()
+    eng.close()
+    ub, rb = _run(n, _lib.MG_PREC_DOUBLE, 1, 0.0, 3, u0=2.0 * u0)
+    assert np.array_equal(ua, ub)
