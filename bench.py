@@ -256,12 +256,26 @@ def main():
             "down_leg": leg("down_leg", dtype, w, 3.25, 2 * 3.0 + 2.25),             # 2 sweeps + residual + restriction
             "up_leg": leg("up_leg", dtype, w, 3.25, 2.25 + 2 * 3.0 + 2.0),           # prolong-add + 2 sweeps + norm
         }
+        # the spanning leg (up leg of cycle k + down leg of cycle k + 1 in one launch, mg_config.speculate = 2): reads u, rhs,
+        # e/4; writes u' and rhs_coarse/4 (3.5 w), plus the iterate in between (4.5 w) when a cycle may end the solve
+        try:
+            kern[name]["span_leg"] = leg("span_leg", dtype, w, 4.5, 2.25 + 4 * 3.0 + 2.0 + 2.25)
+            kern[name]["span_leg_nomid"] = leg("span_leg_nomid", dtype, w, 3.5, 2.25 + 4 * 3.0 + 2.0 + 2.25)
+        except Exception:
+            pass                                                                     # this hierarchy runs the two-launch form
     f32_cycles = sum(1 for c in codes if c == 0)
     f64_cycles = K - f32_cycles
-    t32 = f32_cycles * (kern["f32"]["down_leg"]["launch_ms"] + kern["f32"]["up_leg"]["launch_ms"])
-    t64 = f64_cycles * (kern["f64"]["down_leg"]["launch_ms"] + kern["f64"]["up_leg"]["launch_ms"])
+    # the timed region is mg_iterate(tol = 0, K): with a spanning leg every cycle but the first and the last is one
+    # span_leg_nomid launch on level 0 (nothing can end the solve, the iterate in between is not stored)
+    def level0_ms(p):
+        k = kern[p]
+        return k["span_leg_nomid"]["launch_ms"] if "span_leg_nomid" in k else k["down_leg"]["launch_ms"] + k["up_leg"]["launch_ms"]
+    t32, t64 = f32_cycles * level0_ms("f32"), f64_cycles * level0_ms("f64")
     dom_p = "f64" if t64 >= t32 else "f32"
-    dom_k = "up_leg" if kern[dom_p]["up_leg"]["launch_ms"] >= kern[dom_p]["down_leg"]["launch_ms"] else "down_leg"
+    if "span_leg_nomid" in kern[dom_p]:
+        dom_k = "span_leg_nomid"
+    else:
+        dom_k = "up_leg" if kern[dom_p]["up_leg"]["launch_ms"] >= kern[dom_p]["down_leg"]["launch_ms"] else "down_leg"
     dom = kern[dom_p][dom_k]
     traffic, traffic_source, traffic_build = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -278,7 +292,9 @@ def main():
         except Exception:
             traffic = None
     roof = {"bound": "hbm",
-            "kernel": f"rb_leg_kernel {dom_k} {dom_p} at {n}^2 (level 0, register-blocked fused leg): the largest time share of the timed region",
+            "kernel": (f"rb_span_kernel {dom_p} at {n}^2 (level 0: up leg of cycle k + down leg of cycle k + 1 in one launch, the "
+                       "iterate in between not stored): the largest time share of the timed region") if dom_k.startswith("span")
+                      else f"rb_leg_kernel {dom_k} {dom_p} at {n}^2 (level 0, register-blocked fused leg): the largest time share of the timed region",
             "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
             "traffic_source": traffic_source, "traffic_build": traffic_build, "build": build_now,
             "traffic_is_from_this_build": bool(traffic_build) and traffic_build == build_now,
@@ -294,7 +310,7 @@ def main():
                              "note": "stream_ceiling = a stencil-free c = a + b kernel over the same rotating buffers, timed in this "
                                      "run: what the memory system delivers for 2 reads + 1 write of this size; the sweep runs "
                                      "at frac_of_stream_ceiling of it"},
-            "note": "achieved = bytes the launch must move (3.25 words/DoF for a fused leg, 3 for a sweep) / hipEvent-timed "
+            "note": "achieved = bytes the launch must move (3.5 words/DoF for the spanning leg, 3.25 for a fused leg, 3 for a sweep) / hipEvent-timed "
                     "launch time; unfused_equivalent_* prices the same work as one launch per operator (SURVEY 8d) and may "
                     "exceed the HBM peak",
             "kernels": kern}

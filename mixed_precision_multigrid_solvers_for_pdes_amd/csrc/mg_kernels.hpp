@@ -1684,6 +1684,7 @@ struct FusedArgs {
   int tiles_j, ntiles;
   int nsweep;
   int nsweep2;                  // spanning leg (rb_span_kernel): pre sweeps of the following cycle (nsweep: post sweeps of this one)
+  int band;                     // spanning leg: tile rows per band (tiles are numbered down the columns of a band: see the kernel)
   int colour_offset;            // parity of the global index of local cell (0,0) (red-black colouring)
   int use_div;                  // 1: divide by the diagonal (1/D not exact)
   int nxc, nyc, ldc;            // coarse level (restriction target / prolongation source)

@@ -321,7 +321,7 @@ mg::FusedArgs fused_args(int nx, int ny, int ld, int nsweep, bool use_div, int n
   const int tiles_i = (nx - 2 + TI - 1) / TI;
   a.tiles_j = (ny - 1 + S::TJ - 1) / S::TJ;
   a.ntiles = tiles_i * a.tiles_j;
-  a.nsweep = nsweep; a.use_div = use_div ? 1 : 0; a.colour_offset = poff & 1;
+  a.nsweep = nsweep; a.nsweep2 = 0; a.band = 1; a.use_div = use_div ? 1 : 0; a.colour_offset = poff & 1;
   a.nxc = nxc; a.nyc = nyc; a.ldc = ldc;
   a.ci_off = a.cj_off = 0; a.sides = mg::kAllSides;
   a.ni_lo = 1; a.ni_hi = nx - 1; a.nj_lo = 1; a.nj_hi = ny - 1;
@@ -553,6 +553,8 @@ int launch_span_rb(const void* u, const void* rhs, void* out_mid, void* out_next
   const Coef c = coefs(g.hx, g.hy, g.sigma);
   mg::FusedArgs a = rb_args<T, HALO, W, RPT>(g, !c.pow2);
   a.nsweep2 = nsweep_pre;
+  static const int band = std::max(1, exp_env("MG_EXP_SPAN_BAND", 4));      // measurement builds: other band heights
+  a.band = band;
   const bool nt = rb_stream(g, sizeof(T));
   auto k = out_mid ? (nt ? mg::rb_span_kernel<T, HALO, TX, TC, 2, SM, W, RPT, 1> : mg::rb_span_kernel<T, HALO, TX, TC, 1, SM, W, RPT, 1>)
                    : (nt ? mg::rb_span_kernel<T, HALO, TX, TC, 2, SM, W, RPT, 2> : mg::rb_span_kernel<T, HALO, TX, TC, 1, SM, W, RPT, 2>);
@@ -2106,8 +2108,12 @@ int mg_time_op(mg_handle* h, int op, int level, int dtype, int reps, double* avg
                   d_sweeps(h->cfg.smoother, dt, v.u[dt], v.rhs[dt], v.t[dt], g, h->stream);
                   std::swap(v.u[dt], v.t[dt]); } break;
         case 12: case 13: {                                                                      // spanning leg, with / without the store of the iterate in between
-                  if (level != 0 || !span_ok(h) || h->level_dtype(0) != dt) return MG_ERR_INVALID_VALUE;
-                  const int rc2 = cycle_span(h, op == 12); if (rc2 != MG_OK) return rc2; } break;
+                  const int phase0 = h->phase;
+                  if (h->cfg.precision == MG_PREC_ADAPTIVE) h->phase = dt;                       // time the leg of either working precision
+                  const bool ok = level == 0 && span_ok(h) && h->level_dtype(0) == dt;
+                  const int rc2 = ok ? cycle_span(h, op == 12) : MG_ERR_INVALID_VALUE;
+                  h->phase = phase0;
+                  if (rc2 != MG_OK) return rc2; } break;
         default: return MG_ERR_INVALID_VALUE;
       }
     }

@@ -31,6 +31,10 @@ for smoother, names in ((_lib.MG_JACOBI, [o for o in ops if o != "rbgs" and not 
     eng.cycle(1)
     for dt, w in ((np.float32, 4), (np.float64, 8)):
         for op in names:
-            ms = eng.time_op(op, 0, dt, reps)
+            try:
+                ms = eng.time_op(op, 0, dt, reps)
+            except Exception as exc:                      # e.g. no spanning leg for this hierarchy / precision
+                print(f"{op:14s} {np.dtype(dt).name}: not available ({exc})")
+                continue
             print(f"{op:14s} {np.dtype(dt).name}: {ms * 1e3:9.2f} us/launch   ({n * n * w / ms / 1e6:8.1f} GB/s per word/DoF)")
     eng.close()

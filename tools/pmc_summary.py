@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """profiles/pmc_latest.json from the two rocprofv3 counter passes of tools/kernel_probe.py.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python3 tools/kernel_probe.py 4097 10 jacobi sweeps2 down_leg up_leg
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python3 tools/kernel_probe.py 4097 10 jacobi sweeps2 down_leg up_leg
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python3 tools/kernel_probe.py 4097 10 jacobi sweeps2 down_leg up_leg span_leg span_leg_nomid
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python3 tools/kernel_probe.py 4097 10 jacobi sweeps2 down_leg up_leg span_leg span_leg_nomid
     python3 tools/pmc_summary.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv profiles/pmc_latest.json
 
 Counter values are KB; FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced streaming read:
@@ -24,6 +24,10 @@ fetch_csv, write_csv, out = sys.argv[1:4]
 
 
 def classify(name):
+    # the spanning leg: <T, HALO, TX, TC, TAG, SM, W, RPT, SPAN> (SPAN 1: the iterate in between is stored, 2: not)
+    m = re.search(r"mg::rb_span_kernel<(float|double), \d+, \w+, \w+, [12], 0, \d+, \d+, ([12])>", name)
+    if m:
+        return f"span_leg{'' if m.group(2) == '1' else '_nomid'}_{'f32' if m.group(1) == 'float' else 'f64'}_{N}"
     m = re.search(r"mg::jacobi_kernel<(float|double), 1,", name)
     if m:
         return f"jacobi_sweep_{'f32' if m.group(1) == 'float' else 'f64'}_{N}"
@@ -56,7 +60,7 @@ def collect(path, counter):
 
 fetch, write = collect(fetch_csv, "FETCH_SIZE"), collect(write_csv, "WRITE_SIZE")
 w = {"f32": 4, "f64": 8}
-words = {"jacobi_sweep": 3.0, "jacobi_2sweeps": 3.0, "down_leg": 3.25, "up_leg": 3.25}
+words = {"jacobi_sweep": 3.0, "jacobi_2sweeps": 3.0, "down_leg": 3.25, "up_leg": 3.25, "span_leg": 4.5, "span_leg_nomid": 3.5}
 kernels = {}
 for key in sorted(fetch):
     kind, dt = key.rsplit("_", 2)[0], key.rsplit("_", 2)[1]
@@ -67,7 +71,7 @@ for key in sorted(fetch):
                     "hbm_bytes_per_launch_corrected": hbm, "compulsory_bytes_per_launch": comp,
                     "ratio_to_compulsory": hbm / comp}
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python3 "
-                   "tools/kernel_probe.py 4097 10 jacobi sweeps2 down_leg up_leg` on 1x MI355X, summarised by tools/pmc_summary.py. "
+                   "tools/kernel_probe.py 4097 10 jacobi sweeps2 down_leg up_leg span_leg span_leg_nomid` on 1x MI355X, summarised by tools/pmc_summary.py. "
                    "Values in KB as reported; FETCH_SIZE is doubled (gfx950 counts 1/2 of a wide coalesced streaming read: "
                    "MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact. compulsory = bytes a perfect launch must move "
                    "(fields once).",
