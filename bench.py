@@ -338,9 +338,10 @@ def main():
         tts[name] = to_floor(e2)
         e2.close()
     tts["note"] = ("floor = the plateau of the reference's absolute h-scaled norm (SURVEY F10); time = device-resident mg_iterate to "
-                   "the first cycle within 2x of it.  adaptive: one fp32 cycle, then promoted as soon as ||r|| is within 2x of the "
-                   "fp32 residual floor eps32 * diag(A) * ||u|| (switch_reason); defect: fp32 cycles on the error equation of an "
-                   "fp64 iterate")
+                   "the first cycle within 2x of it.  adaptive: the fp32 phase is entered only where its residual floor eps32 * diag(A) "
+                   "* ||u||, bounded a priori by eps32 * diag(A) / lambda_min * ||r_0||, leaves it at least two cycles (switch_reason "
+                   "fp32_skipped otherwise: 4097^2 and larger), and ends as soon as ||r|| is within 2x of that floor; defect: fp32 "
+                   "cycles on the error equation of an fp64 iterate")
     # ---- the smoother against the stream ceiling by size: does the ceiling climb with launch length? ----
     sweep = []
     for m in (4097, 8193, 16385):
@@ -364,7 +365,7 @@ def main():
     out = {
         "metric": "MDoF/s per V-cycle on 2D Poisson", "value": value, "unit": "MDoF/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32->f64 (adaptive)", "data": "synthetic",
+        "dtype": ("f64" if f32_cycles == 0 else "f32" if f64_cycles == 0 else "f32->f64") + " (adaptive policy)", "data": "synthetic",
         "config": {"workload": f"2D Poisson {n}^2 adaptive fp32->fp64 (switch_threshold=1e-6), V(2,2) weighted-Jacobi "
                                f"omega=0.8, {levels} levels, 1xMI355X", "grid": [n, n], "levels": levels,
                    "cycle": "V(2,2)", "smoother": "jacobi", "parallelism": "1 GPU"},

@@ -104,9 +104,8 @@ typedef struct mg_config {
                                 iteration to coarse_tol (solvers/multigrid.py:119-124, 355-370).  NOT bit-identical to the
                                 reference: the two differ by at most ||A_c^-1|| coarse_tol / h_c ~ 2e-13 per coarsest visit (the
                                 error the iteration is allowed to leave; iterates stay within 1e-12 relative l-inf of the
-                                reference's).  0: always the iteration (bit-identical).  < 0 (the host side's default): direct
-                                in W- and F-cycles, whose 2^(L-1) coarsest visits per cycle are mostly that iteration, the
-                                iteration in V-cycles */
+                                reference's).  0: always the iteration (bit-identical; what the parity tests
+                                run).  < 0 (the host side's default): the same as 1 */
   int32_t mixed_split;       /* MG_PREC_MIXED_LEVELS: first fp32 level; <= 0: num_levels / 2 (core/precision.py:351-357).
                                 Set by a caller whose handle is the lower part of a longer hierarchy (distributed.py: the
                                 replicated coarse levels below the decomposed ones keep the GLOBAL split) */

@@ -853,14 +853,13 @@ int tail_set_attr(size_t bytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) ? MG_OK : MG_ERR_HIP;
 }
 
-// mg_config.coarse_direct: 1 the nine unknowns of a 5 x 5 coarsest grid are solved directly, 0 by the reference's iteration
-// to coarse_tol, < 0 (default) directly in W- and F-cycles -- which visit the coarsest level 2^(L-1) times per cycle and spend
-// most of their time in that iteration -- and by the iteration in V-cycles.
+// mg_config.coarse_direct: 1 or < 0 (the host side's default) the nine unknowns of a 5 x 5 coarsest grid are solved directly,
+// 0 by the reference's iteration to coarse_tol (bit-identical to it; what the parity tests pin).  W- and F-cycles visit the
+// coarsest level 2^(L-1) times per cycle and spent most of their time in that iteration; a V-cycle saves its ~20 sweeps.
 bool want_direct(const mg_handle* h) {
   const int L = h->L();
   if (h->lv[L - 1].nx != 5 || h->lv[L - 1].ny != 5) return false;
-  if (h->cfg.coarse_direct > 0) return true;
-  return h->cfg.coarse_direct < 0 && h->cfg.cycle != MG_CYCLE_V;
+  return h->cfg.coarse_direct != 0;
 }
 
 // Decide where the tail starts: the first level k >= 1 whose sub-hierarchy fits the LDS pool, has at most

@@ -29,9 +29,10 @@ class MultigridEngine:
         lib = _lib.load()
         # coarse_direct: True the nine unknowns of a 5 x 5 coarsest grid are solved directly (u = A^-1 f; within 1e-12 of the
         # reference's iterates, not bit-identical), False by the reference's Gauss-Seidel iteration to coarse_tol (bit-identical),
-        # "auto" directly in W- / F-cycles -- 2^(L-1) coarsest visits per cycle -- and by the iteration in V-cycles; None
-        # (default): what the environment variable MG_COARSE_DIRECT says ("0" / "1" / "auto"), "auto" without it -- the
-        # test suite pins "0" so that its bit-for-bit comparisons between engine paths hold for every cycle type.
+        # "auto" = True (W- / F-cycles visit the coarsest grid 2^(L-1) times per cycle and spent most of their time in that
+        # iteration; a V-cycle saves its ~20 sweeps); None (default): what the environment variable MG_COARSE_DIRECT says
+        # ("0" / "1" / "auto"), "auto" without it -- the test suite pins "0": its comparisons with the oracle and between
+        # engine paths are bit for bit.
         # tail: True / 1 the coarse levels run in the register-resident one-workgroup kernel where it applies (dyadic square
         # levels <= 65^2, csrc/mg_tail_kernels.hpp) and in the LDS one elsewhere; 2 the LDS kernel only; False / 0 one launch pair per level.
         # fused: 0 / False one launch per operator; 1 / True fused legs tiled through LDS; 2 (default) the same legs

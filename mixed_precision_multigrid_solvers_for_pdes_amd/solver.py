@@ -46,8 +46,8 @@ class MultigridSolver(BaseSolver):
                  coarse_max_iterations=1000, verbose=False, device_id=0, profile=False, fmg_cycles=0, coarse_direct=None):
         """coarse_direct (ours): how a 5 x 5 coarsest grid is solved.  False: the reference's lexicographic Gauss-Seidel
         iteration to `coarse_tolerance` (solvers/multigrid.py:119-124, 355-370), bit for bit.  True: its nine unknowns
-        directly.  None (default): directly in W- / F-cycles -- they visit the coarsest grid 2^(L-1) times per cycle and
-        spend most of their time in that iteration -- and by the iteration in V-cycles.  A direct solve satisfies
+        directly.  None (default): directly, unless the environment variable MG_COARSE_DIRECT=0 asks for the iteration
+        (W- / F-cycles visit the coarsest grid 2^(L-1) times per cycle and spent most of their time in it).  A direct solve satisfies
         coarse_tolerance exactly; residual histories then agree with the reference's to max(1e-9 relative,
         coarse_tolerance absolute) -- the accuracy the reference's own coarse solver is configured for -- and iterates to
         1e-12 relative (tests/test_gpu_solver.py)."""

@@ -231,14 +231,17 @@ def test_register_tail_with_a_helmholtz_shift_and_odd_sweep_counts():
         assert out[1][1]["residual_history"] == out[2][1]["residual_history"]
 
 
-def test_default_coarsest_solve_is_direct_for_w_cycles_only():
+def test_default_coarsest_solve_is_direct_and_the_iteration_can_be_asked_for():
+    """coarse_direct="auto" (the shipped default): the nine unknowns of the 5 x 5 grid directly, in every cycle shape;
+    False: the reference's iteration (a positive sweep count comes back)"""
     n = 129
     f = O.sine_rhs(n, n)
-    for cyc, expect_direct in (("V", False), ("W", True), ("F", True)):
-        e = mg.MultigridEngine(n, n, max_levels=6, cycle=cyc, smoother=_lib.MG_RBGS, omega=1.0, coarse_direct="auto")
-        u, r = e.solve(f, tol=1e-10, max_iterations=30)
-        assert (r["last_coarse_sweeps"] == 0) == expect_direct and r["converged"]
-        e.close()
+    for cyc in ("V", "W", "F"):
+        for direct, expect_direct in (("auto", True), (True, True), (False, False)):
+            e = mg.MultigridEngine(n, n, max_levels=6, cycle=cyc, smoother=_lib.MG_RBGS, omega=1.0, coarse_direct=direct)
+            u, r = e.solve(f, tol=1e-10, max_iterations=30)
+            assert (r["last_coarse_sweeps"] == 0) == expect_direct and r["converged"]
+            e.close()
 
 
 # ---------------------------------------------------------------- ADVICE r02 ----
