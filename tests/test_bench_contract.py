@@ -1,5 +1,5 @@
 """The bench line the driver parses: every key of the contract, on the line recorded with the final build of the round
-(profiles/r02_bench_final.json = stdout of `python bench.py` on one MI355X)."""
+(profiles/r03_bench_final.json = stdout of `python bench.py` on one MI355X)."""
 import json
 import os
 
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_recorded_bench_line_has_the_contract_keys():
-    line = open(os.path.join(ROOT, "profiles", "r02_bench_final.json")).read().strip()
+    line = open(os.path.join(ROOT, "profiles", "r03_bench_final.json")).read().strip()
     assert "\n" not in line                                   # ONE JSON line
     d = json.loads(line)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
@@ -40,3 +40,12 @@ def test_recorded_bench_line_has_the_contract_keys():
     assert ref["kind"] == "reference" and ref["cores"] == 1 and "4097^2" in ref["sample"] and 20.0 < ref["seconds_per_cycle"] < 40.0
     assert d["iterations"] == d["steps"] and d["residual_floor"] > 0 and 1 <= d["iterations_to_floor"] <= 40
     assert d["iterations_to_1e-10_absolute"] is None                        # unreachable at 4097^2 in fp64: the floor says why
+    # round 3: time to solution per policy, the adaptive policy never behind double, the size sweep
+    t = d["time_to_solution"]
+    for pol in ("adaptive", "double", "defect"):
+        assert t[pol]["iterations_to_floor"] >= 1 and t[pol]["time_to_floor_ms"] > 0
+    assert t["adaptive"]["time_to_floor_ms"] <= 1.05 * t["double"]["time_to_floor_ms"]
+    assert d["switch_reason"] in ("fp32_skipped", "fp32_floor", "threshold", "stagnation")
+    assert [row["n"] for row in d["smoother_size_sweep"]["rows"]] == [4097, 8193, 16385]
+    assert "span" in r["kernel"] and "span_leg_nomid" in r["kernels"]["f64"]      # the spanning leg is the dominant kernel
+    assert r["build"] and ("traffic_is_from_this_build" in r)
