@@ -358,10 +358,10 @@ inline void apply_sub(mg::FusedArgs& a, const LegGeom& g) {
 inline bool small_tiles(const LegGeom& g, int sm = mg::kSmJacobi) {
   return (long long)g.nx * g.ny <= 1100LL * 1100LL || (g.acoef && sm == mg::kSmRbgs);
 }
-// 8-row tiles: constant-coefficient legs on levels of <= ~520^2 cells (513^2 and below) (MG_EXP_TINY=n: up to n^2 cells, 0 keeps the 16-row tiles: experiments)
+// 8-row tiles: legs on levels of <= ~520^2 cells (513^2 and below) (MG_EXP_TINY=n: up to n^2 cells, 0 keeps the 16-row tiles: experiments)
 inline bool tiny_tiles(const LegGeom& g) {
   static const long long lim = exp_env("MG_EXP_TINY", 520);   // 0: off
-  return lim > 0 && !g.acoef && (long long)g.nx * g.ny <= lim * lim;
+  return lim > 0 && (long long)g.nx * g.ny <= lim * lim;
 }
 
 template <typename T, typename TX, int SM, int TI>
