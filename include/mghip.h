@@ -292,6 +292,20 @@ int mg_dev_up_leg_var(int smoother, int dtype, int coarse_dtype, int compute_dty
                       int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep, int colour_offset,
                       const void* u, const void* rhs, void* out, const void* e_coarse, int norm, int ni_lo, int ni_hi, int nj_lo,
                       int nj_hi, void* scratch, double* sumsq_dev, void* stream, const void* acoef, const void* rdiag);
+/* The spanning leg (csrc/mg_rb_kernels.hpp, rb_span_kernel): mg_dev_up_leg of cycle k (u += P e_coarse, nsweep_post sweeps,
+ * sum r^2 over the window) and mg_dev_down_leg of cycle k + 1 (nsweep_pre sweeps, residual, full weighting into rhs_coarse) in
+ * ONE pass over `u`: the iterate of cycle k goes to `out_mid` (may be NULL when nobody will read it), the pre-smoothed iterate of
+ * cycle k + 1 to `out_next`; u, out_mid, out_next are three different arrays of one shape.  Same bits as the two calls.
+ * Weighted Jacobi, constant coefficients, fine and coarse field of one dtype, arrays above ~1100^2 cells (what the
+ * register-blocked legs serve); anything else returns MG_ERR_INVALID_VALUE and the caller issues the two legs.
+ * mg_dev_span_leg_ok: 1 where the call would be accepted.  Replaces nothing upstream (the reference smooths, restricts and
+ * interpolates one operator at a time, solvers/multigrid.py:289-335). */
+int mg_dev_span_leg_ok(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny);
+int mg_dev_span_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
+                    int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep_post,
+                    int nsweep_pre, int colour_offset, const void* u, const void* rhs, void* out_mid, void* out_next,
+                    const void* e_coarse, void* rhs_coarse, int ni_lo, int ni_hi, int nj_lo, int nj_hi, void* scratch,
+                    double* sumsq_dev, void* stream);
 /* rdiag[i][j] = 1 / ((a(i+1/2) + a(i-1/2)) / hx^2 + (a(j+1/2) + a(j-1/2)) / hy^2 [+ sigma]) on interior cells (face values =
  * arithmetic means of the vertex values), 0 on the ring of the array; rounded once in `dtype` */
 int mg_dev_var_rdiag(int dtype, int nx, int ny, int ld, double hx, double hy, double sigma, const void* a, void* rdiag, void* stream);
@@ -331,7 +345,10 @@ enum {
   MG_PLAN_COARSE_END = 13,    /* i: ld, dtype;  p: engine handle, out */
   MG_PLAN_EVENT_RECORD = 14,  /* i: event id (0..7) on the operation's stream */
   MG_PLAN_STREAM_WAIT = 15,   /* i: event id: the operation's stream waits for it */
-  MG_PLAN_RESULT = 16         /* p: device double copied to the host at the end of mg_plan_run (at most one) */
+  MG_PLAN_RESULT = 16,        /* p: device double copied to the host at the end of mg_plan_run (at most one) */
+  MG_PLAN_SPAN_LEG = 17       /* mg_dev_span_leg -- i: smoother, dtype, coarse_dtype, compute_dtype, nx, ny, ld, nxc, nyc, ldc, ci_off,
+                                 cj_off, sides, nsweep_post, nsweep_pre, colour_offset, ni_lo, ni_hi, nj_lo, nj_hi;  d: hx, hy, omega, coeff;
+                                 p: u, rhs, out_mid (may be NULL), out_next, e_coarse, rhs_coarse, scratch, sumsq_dev */
 };
 typedef struct mg_plan_op {
   int32_t op;       /* MG_PLAN_* */

@@ -61,7 +61,7 @@ class MgPlanOp(C.Structure):
 
 (MG_PLAN_DOWN_LEG, MG_PLAN_UP_LEG, MG_PLAN_COPY2D, MG_PLAN_ADD_F64, MG_PLAN_GROUP_BEGIN, MG_PLAN_SEND, MG_PLAN_RECV,
  MG_PLAN_GROUP_END, MG_PLAN_ALLGATHER, MG_PLAN_ALLREDUCE_F64, MG_PLAN_COARSE_BEGIN, MG_PLAN_COARSE_CYCLE, MG_PLAN_COARSE_END,
- MG_PLAN_EVENT_RECORD, MG_PLAN_STREAM_WAIT, MG_PLAN_RESULT) = range(1, 17)
+ MG_PLAN_EVENT_RECORD, MG_PLAN_STREAM_WAIT, MG_PLAN_RESULT, MG_PLAN_SPAN_LEG) = range(1, 18)
 
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
 _pi, _pd = C.POINTER(C.c_int), C.POINTER(C.c_double)
@@ -120,6 +120,8 @@ SIGNATURES = {
     "mg_dev_up_leg": (_i, [_i] * 13 + [_d] * 4 + [_i] * 2 + [_vp] * 4 + [_i] * 5 + [_vp] * 3),
     "mg_dev_down_leg_var": (_i, [_i] * 11 + [_d] * 4 + [_i] * 3 + [_vp] * 5 + [_i, C.POINTER(C.c_int), _vp, _vp]),
     "mg_dev_up_leg_var": (_i, [_i] * 13 + [_d] * 4 + [_i] * 2 + [_vp] * 4 + [_i] * 5 + [_vp] * 5),
+    "mg_dev_span_leg_ok": (_i, [_i] * 6),
+    "mg_dev_span_leg": (_i, [_i] * 13 + [_d] * 4 + [_i] * 3 + [_vp] * 6 + [_i] * 4 + [_vp] * 3),
     "mg_dev_var_rdiag": (_i, [_i] * 4 + [_d] * 3 + [_vp] * 3),
     "mg_dev_inject_ring": (_i, [_i] * 11 + [_vp] * 3),
     "mg_dev_scratch_bytes": (_i, [_i, _i, C.POINTER(C.c_int64)]),

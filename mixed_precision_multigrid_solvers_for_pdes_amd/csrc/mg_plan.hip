@@ -132,7 +132,7 @@ int nccl_fail(mg_plan* p, int rc, const char* what) {
 // phase of an operation for mg_plan_phase_times (include/mghip.h)
 int phase_of(int op) {
   switch (op) {
-    case MG_PLAN_DOWN_LEG: case MG_PLAN_UP_LEG: return 0;
+    case MG_PLAN_DOWN_LEG: case MG_PLAN_UP_LEG: case MG_PLAN_SPAN_LEG: return 0;
     case MG_PLAN_COPY2D: return 1;
     case MG_PLAN_GROUP_BEGIN: case MG_PLAN_SEND: case MG_PLAN_RECV: case MG_PLAN_GROUP_END: return 2;
     case MG_PLAN_ALLGATHER: return 3;
@@ -156,6 +156,9 @@ int check_op(const mg_plan_op& o, int idx, std::string* err) {
       return MG_OK;
     case MG_PLAN_UP_LEG:
       if (!o.p[0] || !o.p[1] || !o.p[2] || !o.p[3] || (o.i[15] && (!o.p[4] || !o.p[5]))) return bad("up leg: NULL field");
+      return MG_OK;
+    case MG_PLAN_SPAN_LEG:
+      if (!o.p[0] || !o.p[1] || !o.p[3] || !o.p[4] || !o.p[5] || !o.p[6] || !o.p[7]) return bad("spanning leg: NULL field");
       return MG_OK;
     case MG_PLAN_COPY2D:
       if (!o.p[0] || !o.p[1] || o.i[0] < 0 || o.i[1] < 0 || (o.i[1] & 3) || (o.i[2] & 3) || (o.i[3] & 3) ||
@@ -438,6 +441,13 @@ int mg_plan_run_async(mg_plan* p, void* compute_stream, void* comm_stream) {
                                          o.d[2], o.d[3], i[13], i[14], o.p[0], o.p[1], o.p[2], o.p[3], i[15], i[16], i[17], i[18], i[19],
                                          o.p[4], static_cast<double*>(o.p[5]), s, o.p[6], o.p[7]);
         if (rc != MG_OK) return lib_fail(rc, static_cast<int>(k), "up leg");
+        break;
+      }
+      case MG_PLAN_SPAN_LEG: {
+        const int rc = mg_dev_span_leg(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], o.d[0], o.d[1],
+                                       o.d[2], o.d[3], i[13], i[14], i[15], o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], i[16], i[17],
+                                       i[18], i[19], o.p[6], static_cast<double*>(o.p[7]), s);
+        if (rc != MG_OK) return lib_fail(rc, static_cast<int>(k), "spanning leg");
         break;
       }
       case MG_PLAN_COPY2D: {

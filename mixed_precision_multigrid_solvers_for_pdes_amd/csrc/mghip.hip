@@ -2271,6 +2271,35 @@ int mg_dev_up_leg_var(int smoother, int dtype, int coarse_dtype, int compute_dty
   return MG_OK;
 }
 
+int mg_dev_span_leg_ok(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny) {
+  if (smoother != MG_JACOBI || !valid_dtype(dtype) || coarse_dtype != dtype || !valid_dtype(compute_dtype)) return 0;
+  if (dtype == MG_F64 && compute_dtype != MG_F64) return 0;
+  LegGeom g{nx, ny, 0, 0, 0, 0, 1.0, 1.0, 0, 0, 0, 0, false};
+  g.rb = 1;
+  return use_rb(g, mg::kSmJacobi) ? 1 : 0;
+}
+
+int mg_dev_span_leg(int smoother, int dtype, int coarse_dtype, int compute_dtype, int nx, int ny, int ld, int nxc, int nyc, int ldc,
+                    int ci_off, int cj_off, int sides, double hx, double hy, double omega, double coeff, int nsweep_post,
+                    int nsweep_pre, int colour_offset, const void* u, const void* rhs, void* out_mid, void* out_next,
+                    const void* e_coarse, void* rhs_coarse, int ni_lo, int ni_hi, int nj_lo, int nj_hi, void* scratch,
+                    double* sumsq_dev, void* stream) {
+  CHECK_DEV(mg_dev_span_leg_ok(smoother, dtype, coarse_dtype, compute_dtype, nx, ny), "mg_dev_span_leg: weighted Jacobi on one dtype and arrays above ~1100^2 cells only");
+  CHECK_DEV(nx >= 3 && ny >= 3 && nxc >= 2 && nyc >= 2 && ld_ok(dtype, ny, ld) && ldc >= nyc && nsweep_post >= 1 && nsweep_post <= 2 &&
+            nsweep_pre >= 1 && nsweep_pre <= 2 && sides >= 0 && sides <= 15, "mg_dev_span_leg: bad shape / pitch / sweep count");
+  CHECK_DEV(u && rhs && out_next && e_coarse && rhs_coarse && scratch && sumsq_dev && u != out_next && u != out_mid && out_mid != out_next &&
+            aligned16(u) && aligned16(rhs) && aligned16(out_next) && (!out_mid || aligned16(out_mid)), "mg_dev_span_leg: bad pointer");
+  LegGeom g{nx, ny, ld, nxc, nyc, ldc, hx, hy, omega, coeff, nsweep_post, colour_offset, false};
+  g.ci_off = ci_off; g.cj_off = cj_off; g.sides = sides;
+  g.ni_lo = ni_lo; g.ni_hi = ni_hi; g.nj_lo = nj_lo; g.nj_hi = nj_hi;
+  g.rb = 1;
+  const int n = d_span(dtype, compute_dtype, u, rhs, out_mid, out_next, e_coarse, rhs_coarse, (double*)scratch, g, nsweep_pre, (hipStream_t)stream);
+  if (n < 0) return fail(nullptr, MG_ERR_INVALID_VALUE, "mg_dev_span_leg: unsupported precision combination");
+  launch_reduce((double*)scratch, n, sumsq_dev, (hipStream_t)stream);
+  HIPC(nullptr, hipGetLastError());
+  return MG_OK;
+}
+
 int mg_dev_var_rdiag(int dtype, int nx, int ny, int ld, double hx, double hy, double sigma, const void* a, void* rdiag, void* stream) {
   CHECK_DEV(valid_dtype(dtype) && nx >= 3 && ny >= 3 && ld_ok(dtype, ny, ld) && sigma >= 0.0, "mg_dev_var_rdiag: bad shape / pitch / shift");
   CHECK_DEV(a && rdiag && a != rdiag, "mg_dev_var_rdiag: bad pointer");

@@ -247,6 +247,28 @@ class HipOps:
                           d=(hx, hy, omega, coeff), p=(u, rhs, out, e_c, self.scratch, res, acoef, rdiag))
         return res if window is not None else None
 
+    def span_ok(self, sm, u, e_c, lnx, lny):
+        """the spanning leg serves this block (weighted Jacobi, one dtype, above ~1100^2 cells: include/mghip.h)"""
+        return bool(self.lib.mg_dev_span_leg_ok(sm, self._code(u), self._code(e_c), self.comp_dt, lnx, lny))
+
+    def span_leg(self, sm, u, rhs, out_mid, out_next, e_c, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff,
+                 nsweep_post, nsweep_pre, poff, window):
+        """up_leg of cycle k (u -> out_mid, sum r^2 over `window`) and down_leg of cycle k + 1 (-> out_next, rhs_c) in one
+        launch (mg_dev_span_leg); returns the sum as a device tensor"""
+        res = self.torch.empty(1, dtype=self.torch.float64, device=self.device)
+        self._scratch_for(lnx, lny)
+        w = window
+        _lib.check(self.lib.mg_dev_span_leg(sm, self._code(u), self._code(e_c), self.comp_dt, lnx, lny, u.stride(0), lnxc, lnyc,
+                                            e_c.stride(0), ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep_post, nsweep_pre, poff,
+                                            self._p(u), self._p(rhs), self._p(out_mid), self._p(out_next), self._p(e_c), self._p(rhs_c),
+                                            w[0], w[1], w[2], w[3], self._p(self.scratch), self._p(res), self._stream()))
+        if self.rec is not None:
+            self.rec.emit(_lib.MG_PLAN_SPAN_LEG,
+                          i=(sm, self._code(u), self._code(e_c), self.comp_dt, lnx, lny, u.stride(0), lnxc, lnyc, e_c.stride(0), ci_off,
+                             cj_off, sides, nsweep_post, nsweep_pre, poff) + tuple(w),
+                          d=(hx, hy, omega, coeff), p=(u, rhs, out_mid, out_next, e_c, rhs_c, self.scratch, res))
+        return res
+
     def inject_ring(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides, ci_off, cj_off):
         _lib.check(self.lib.mg_dev_inject_ring(self._code(fine), self._code(coarse), lnxf, lnyf, fine.stride(0), lnxc, lnyc,
                                                coarse.stride(0), sides, ci_off, cj_off, self._p(fine), self._p(coarse), self._stream()))
@@ -364,8 +386,12 @@ class DistributedMultigrid:
 
     def __init__(self, NX, NY, px, py, ranks, ops, dist=None, domain=(0.0, 1.0, 0.0, 1.0), coeff=-1.0,
                  max_levels=None, cycle="V", pre=2, post=2, smoother="jacobi", omega=0.8, coarse_tol=1e-12,
-                 coarse_maxit=1000, agglomerate_at=1025, mode="auto", overlap=True, native="auto"):
-        """native: replay the cycle from a recorded plan (dist_plan.py; one C call per cycle).  "auto": whenever the
+                 coarse_maxit=1000, agglomerate_at=1025, mode="auto", overlap=True, native="auto", span="auto"):
+        """span: run the level-0 up leg of cycle k and the down leg of cycle k + 1 as ONE launch (ops.span_leg) whenever the
+        next cycle's front part is queued ahead of the norm anyway (`speculate`): "auto" with native plans (MG_DIST_SPAN=0
+        turns it off), True also in the eager driver (tests), False never.  Weighted Jacobi, constant coefficients, level 0
+        and level 1 in one dtype, blocks the kernel serves (ops.span_ok); same iterates bit for bit.
+        native: replay the cycle from a recorded plan (dist_plan.py; one C call per cycle).  "auto": whenever the
         kernels are the device ones, the mode is "fused" and the ranks talk over RCCL (or live in this process).
         Precision: every level in ops.np_dtype, or -- with an `ops` built for per-level mixed precision (ops.mixed:
         PrecisionManager('mixed'), core/precision.py:337-357) -- level l >= L // 2 in fp32 and the rest, like the
@@ -406,6 +432,7 @@ class DistributedMultigrid:
             d.rank, d.rx, d.ry = r, rx, ry
             d.blk = [Block(a, b, px, py, rx, ry, self.G) for (a, b) in self.shapes[:self.Ld + 1]]
             d.u, d.t, d.rhs, d.r, d.a, d.rd = [], [], [], [], [], []
+            d.s = [None] * self.Ld                 # level 0 only: third buffer of the spanning leg, allocated on first use
             for l in range(self.Ld):
                 b = d.blk[l]
                 d.u.append(ops.alloc(b.lnx, b.lny, self.ldt[l]))
@@ -444,6 +471,7 @@ class DistributedMultigrid:
             # RCCL call on a communicator must reach it from one stream (dist_plan.shared_comm_stream)
             self._comm_stream = dist_plan.shared_comm_stream(getattr(ops, "device", torch.device("cuda", torch.cuda.current_device())))
             self._ev_a, self._ev_b = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_c, self._ev_d = torch.cuda.Event(), torch.cuda.Event()      # spanning mode: the level-0 exchange beside the lower levels
         # native replay of the cycle (dist_plan.py)
         plan_ok = (self.mode == "fused" and getattr(ops, "plan_capable", False) and self.Ld > 0 and
                    (dist is None or dist.get_backend() == "nccl"))
@@ -453,6 +481,13 @@ class DistributedMultigrid:
             raise ValueError("native cycle plans need the device kernels, mode 'fused' and RCCL (or in-process ranks)")
         self.native = plan_ok if native == "auto" else bool(native)
         self.native_required = native is True
+        if span not in ("auto", True, False):
+            raise ValueError(f"Unknown span setting: {span}")
+        self.span = (self.native and os.environ.get("MG_DIST_SPAN", "1") != "0") if span == "auto" else bool(span)
+        self._pre = None                         # spanning mode: the level-0 buffer ("t" / "s") holding the queued front part's pre-smoothed iterate
+        self._sp_plans = {}                      # ... its recorded plans: ("mid", src) -> (legs + norm, lower levels), ("back", src) -> plan
+        self._norm_plan = None                   # the plan whose RESULT (sum of r^2) is in flight
+        self._plan_x = {}                        # plan -> halo exchanges it issues (statistics)
         self.native_failure = None               # why "auto" fell back to the Python driver, if it did
         self._plan_exchanges = 0
         self._rec = None                         # PlanRecorder while the first cycle is being recorded
@@ -478,9 +513,8 @@ class DistributedMultigrid:
         CPU stand-in.  For diagnostic cycles outside a timed region; collect_phase_times() returns milliseconds per phase."""
         self.phase_times = {n: 0.0 for n in _lib.PLAN_PHASE_NAMES} if enable else None
         self._phase_events = []
-        for pl in (self._plan, self._plan_back):
-            if pl is not None:
-                pl.profile(enable)
+        for pl in self._all_plans():
+            pl.profile(enable)
 
     def collect_phase_times(self):
         if self.phase_times is None:
@@ -490,9 +524,8 @@ class DistributedMultigrid:
             for name, e0, e1 in self._phase_events:
                 self.phase_times[name] += e0.elapsed_time(e1)
             self._phase_events = []
-        for pl in (self._plan, self._plan_back):
-            if pl is not None:
-                pl.phase_times(self.phase_times)
+        for pl in self._all_plans():
+            pl.phase_times(self.phase_times)
         out = dict(self.phase_times)
         for k in self.phase_times:
             self.phase_times[k] = 0.0
@@ -712,8 +745,13 @@ class DistributedMultigrid:
             raise RuntimeError("single-block problems go through MultigridEngine")
         self._last_norm_parts = None
         self._norm_value = None
+        spanning = l == 0 and not zero_u and self._span_usable()
         if self.native and l == 0 and not zero_u:
-            return self._cycle_native()
+            return self._cycle_native_span() if spanning else self._cycle_native()
+        if spanning:
+            if self._norm_pending or self._front_queued:      # native cycles came before: start from their iterate
+                self._settle()
+            return self._cycle_span_eager()
         # an eager cycle after native ones: collect a norm still in flight and forget a queued front part -- it was computed
         # from the iterate this cycle is about to replace
         self._settle()
@@ -724,27 +762,132 @@ class DistributedMultigrid:
     # ---- native replay (dist_plan.py) --------------------------------------------------------------
     def _pointer_state(self):
         return tuple((d.u[l].data_ptr(), d.t[l].data_ptr(), d.rhs[l].data_ptr(), 0 if d.a[l] is None else d.a[l].data_ptr(),
-                      0 if d.rd[l] is None else d.rd[l].data_ptr())
+                      0 if d.rd[l] is None else d.rd[l].data_ptr(), 0 if d.s[l] is None else d.s[l].data_ptr())
                      for d in self.doms.values() for l in range(self.Ld)) + \
             tuple(0 if d.ring_sumsq is None else d.ring_sumsq.data_ptr() for d in self.doms.values()) + (self.var,)
 
+    def _all_plans(self):
+        out = [q for q in (self._plan, self._plan_back) if q is not None]
+        for pair in self._sp_plans.values():
+            out.extend(q for q in pair if q is not None)
+        return out
+
     def _drop_plan(self):
-        if self._plan is not None:
+        plans = self._all_plans()
+        if plans:
             self.torch.cuda.synchronize()
-            self._plan.close()
-            if self._plan_back is not None:
-                self._plan_back.close()
-        self._plan = self._plan_back = None
+            for q in plans:
+                q.close()
+        self._plan = self._plan_back = self._norm_plan = None
+        self._sp_plans = {}
+        self._plan_x = {}
         self._plan_state = None
         self._front_queued = self._norm_pending = False
+        self._pre = None
 
     def _settle(self):
         """Before the iterate is replaced (new problem / coefficient / iterate): collect a norm still in flight and forget a
         front part queued for a cycle that will not come."""
         if self._norm_pending:
-            self._norm_value = self._plan_back.wait()
+            self._norm_value = (self._norm_plan or self._plan_back).wait()
             self._norm_pending = False
         self._front_queued = False
+        self._pre = None                         # spanning mode: u holds the iterate, whatever t / s were being prepared for
+
+    def _record_part(self, fn):
+        """run `fn` through the Python driver with a recorder attached -> CyclePlan (None, and self._plan_failure, if it cannot be built)"""
+        from . import dist_plan
+        device = next(iter(self.doms.values())).u[0].device
+        before = self.exchanges
+        self._rec = self.ops.rec = dist_plan.PlanRecorder()
+        try:
+            fn()
+            rec = self._rec
+        finally:
+            self._rec = self.ops.rec = None
+        try:
+            if self.dist is not None and self._comm is None:
+                self._comm = dist_plan.shared_comm(self.dist, device.index or 0)
+            plan = dist_plan.CyclePlan(rec, self._comm, device.index or 0)
+        except Exception as exc:                 # the work is done; only the replay is missing (agreed on by all ranks below)
+            self._plan_failure = exc
+            return None
+        self._plan_x[plan] = self.exchanges - before
+        if self.phase_times is not None:
+            plan.profile(True)
+        return plan
+
+    def _cycle_native_span(self):
+        """The spanning scheme with recorded plans: front F (u -> t, lower levels), and per source buffer a mid pair (spanning
+        legs + norm | exchange + lower levels) and a back plan (up legs + norm).  Each is recorded from the Python driver the
+        first time its turn comes (that cycle runs eagerly) and replayed afterwards; the norm travels behind the legs' plan."""
+        torch = self.torch
+        if self._plan is not None and getattr(self, "_plan_kind", None) != "span":      # plans of the two-launch scheme
+            self._settle()
+            self._drop_plan()
+        self._ensure_third()
+        state = self._pointer_state()
+        if (self._plan is not None or self._sp_plans) and self._plan_state != state:
+            self._settle()
+            self._drop_plan()
+        comm = self._comm_stream.cuda_stream if self.overlap else torch.cuda.current_stream().cuda_stream
+        compute = torch.cuda.current_stream().cuda_stream
+        if self._norm_pending:                   # nobody asked for the previous cycle's norm
+            (self._norm_plan or self._plan_back).wait()
+            self._norm_pending = False
+        replayed = True
+        self._plan_failure = None
+        if self._pre is None:
+            if self._plan is None:
+                self._plan = self._record_part(lambda: (self._sp_front("t"), self._sp_lower("t")))
+                self._plan_state, self._plan_kind = state, "span"
+                replayed = False
+            else:
+                self._plan.run_async(compute, comm)
+                self.exchanges += self._plan_x[self._plan]
+            self._pre = "t"
+        src = self._pre
+        dst = ("s" if src == "t" else "t") if self.speculate else None
+        key = ("mid" if dst else "back", src)
+        plans = self._sp_plans.get(key)
+        if plans is None:
+            def legs():
+                self._sp_legs(src, dst)
+                self._norm_value = self.allreduce_sum(self._last_norm_parts)
+            first = self._record_part(legs)
+            self._last_norm_parts = None
+            second = self._record_part(lambda: self._sp_lower(dst)) if dst else None
+            self._sp_plans[key] = (first, second)
+            replayed = False
+        else:
+            for q in plans:
+                if q is not None:
+                    q.run_async(compute, comm)
+                    self.exchanges += self._plan_x[q]
+            self._norm_plan, self._norm_pending = plans[0], True
+        self._pre = dst
+        if not replayed:
+            # a rank that could not build a plan takes every rank back to the Python driver -- agreed on through
+            # torch.distributed (every rank records in the same cycle), so nobody replays alone
+            failure = self._plan_failure
+            if self.dist is not None:
+                device = next(iter(self.doms.values())).u[0].device
+                flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device=device)
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+                if int(flag.item()) and failure is None:
+                    failure = RuntimeError("another rank could not build its cycle plan")
+            if failure is not None:
+                if self.native_required:
+                    raise failure
+                norm = self._norm_value
+                self._drop_plan()                # also forgets the queued front part: the eager driver starts from the iterate in u
+                self._norm_value = norm
+                self.native = False
+                self.native_failure = repr(failure)
+                return
+        self._front_queued = self._pre is not None
+        if replayed:
+            self.native_cycles += 1
 
     def _cycle_native(self):
         """The first cycle (and the first after anything moved a field to another buffer) runs through the Python driver
@@ -753,9 +896,10 @@ class DistributedMultigrid:
         from . import dist_plan
         torch = self.torch
         state = self._pointer_state()
-        if self._plan is not None and self._plan_state != state:
+        if self._plan is not None and (self._plan_state != state or getattr(self, "_plan_kind", None) == "span"):
             self._settle()
             self._drop_plan()
+        self._plan_kind = "plain"
         if self._plan is None:
             device = next(iter(self.doms.values())).u[0].device
             before = self.exchanges
@@ -814,31 +958,22 @@ class DistributedMultigrid:
         self.native_cycles += 1
         self.exchanges += self._plan_exchanges
 
-    def _cycle_fused(self, l, zero_u, first_visit_rhs=False):
-        """Two launches and (at most) two exchanges per level.  Validity bookkeeping (m = cells of the ghost zone that
-        are exact, counted from the owned cells outwards; G = 7): after an exchange m = 7; the down leg's two sweeps
-        leave the iterate exact on m = 5, its restriction is exact on all owned coarse cells; the correction that
-        comes back from below is exact on m_c >= 3 coarse cells = 6 fine cells, so after the up leg (prolongation,
-        two sweeps) m = min(5, 6) - 2 = 3 >= 0, and the norm (one more cell) only reads exact values."""
+    def _down_legs(self, l, zero_u, pending, out=None):
+        """The down legs of level l on every local block: u -> `out` (rank -> array; default the ping-pong partner t), the
+        restricted residual -> the level below.  `pending`: fields of this level whose ghost zones the legs wait for; with
+        overlap the exchange runs on the communication stream beside the tiles that read no ghost data."""
         hx, hy = self.h[l]
         last = (l + 1 == self.Ld)
-        # What this level's down leg is waiting for: the iterate's ghost zone (level 0 every cycle; coarser levels only
-        # when re-visited by a W / F cycle) and, below level 0, the ghost zone of the rhs the level above just produced.
-        pending = []
-        if not zero_u:
-            pending.append("u")
-        if l > 0 and first_visit_rhs:
-            pending.append("rhs")
 
         def down(select, inner_of):
-            for d in self.doms.values():
+            for r, d in self.doms.items():
                 b, bc = d.blk[l], d.blk[l + 1]
                 ci, cj = b.coarse_offsets(bc)
                 target = d.rc if last else d.rhs[l + 1]
                 kw = {"acoef": d.a[l], "rdiag": d.rd[l]} if self.var else {}
                 with self._ph("legs"):
-                    self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l], target, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, hx, hy,
-                                      self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1,
+                    self.ops.down_leg(self.smk, d.u[l], d.rhs[l], d.t[l] if out is None else out[r], target, b.lnx, b.lny, bc.lnx, bc.lny,
+                                      ci, cj, hx, hy, self.omega, self.coeff, self.pre, zero_u, (b.gx0 + b.gy0) & 1,
                                       select, inner_of(b) if select else None, **kw)
 
         def inner_rect(b):      # cells whose values do not come out of an exchange: owned cells and physical boundary
@@ -873,6 +1008,122 @@ class DistributedMultigrid:
             for name in pending:
                 self.exchange(name, l)
             down(0, None)
+
+    # ---- level 0 with a spanning leg ------------------------------------------------------------------------------------
+    # Three level-0 arrays per block: u ALWAYS holds the iterate of the last completed cycle; t and s take turns holding the
+    # pre-smoothed iterate of the cycle in flight (self._pre names the one that does).  front: u -> t (down legs);
+    # mid: src -> u (iterate of this cycle) and -> the other one (pre-smoothed iterate of the next), one launch; back: src -> u
+    # (up legs).  Every part ends with the level-0 ghost zones of what it just wrote on their way (beside the lower levels), so
+    # that the part that follows -- mid or back -- reads m = 7 exact ghost cells: post sweeps leave 4, the norm reads owned
+    # cells, pre sweeps leave 2, residual 1, full weighting of the owned coarse cells needs 1.
+    def _f0(self, d, name):
+        return d.u[0] if name == "u" else (d.t[0] if name == "t" else d.s[0])
+
+    def _span_usable(self):
+        if not (self.span and self.mode == "fused" and self.smoother == "jacobi" and not self.var and self.Ld >= 1 and
+                1 <= self.pre <= 2 and 1 <= self.post <= 2 and hasattr(self.ops, "span_leg") and self.ldt[0] == self.ldt[1]):
+            return False
+        for d in self.doms.values():
+            b = d.blk[0]
+            if not self.ops.span_ok(self.smk, d.u[0], d.ec if self.Ld == 1 else d.u[1], b.lnx, b.lny):
+                return False
+        return True
+
+    def _ensure_third(self):
+        for d in self.doms.values():
+            if d.s[0] is None:
+                b = d.blk[0]
+                d.s[0] = self.ops.alloc(b.lnx, b.lny, self.ldt[0])
+                d.s[0].copy_(d.u[0])               # the outermost ring (Dirichlet values on physical edges) is never written by a leg
+
+    def _sp_front(self, dst):
+        self._down_legs(0, False, ["u"], out={r: self._f0(d, dst) for r, d in self.doms.items()})
+
+    def _sp_lower(self, xname):
+        """everything below level 0 of one cycle, the halo exchange of the level-0 array `xname` beside it"""
+        torch, rec = self.torch, self._rec
+        if self.overlap:
+            compute = torch.cuda.current_stream()
+            self._ev_c.record(compute)
+            if rec is not None:
+                rec.event_record(2)
+                rec.stream = 1
+                rec.stream_wait(2)
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(self._ev_c)
+                self.exchange(xname, 0)
+                self._ev_d.record(self._comm_stream)
+            if rec is not None:
+                rec.event_record(3)
+                rec.stream = 0
+        else:
+            self.exchange(xname, 0)
+        if self.Ld == 1:
+            self._replicated_cycle(0)
+        else:
+            for k in range(self._reps(0)):
+                self._cycle_fused(1, k == 0, k == 0)
+        if self.overlap:
+            compute.wait_event(self._ev_d)
+            if rec is not None:
+                rec.stream_wait(3)
+
+    def _sp_legs(self, src, dst):
+        """dst None: the up legs src -> u (back part); else the spanning legs src -> u and dst (mid part).  Sets the norm parts."""
+        hx, hy = self.h[0]
+        parts = {}
+        for r, d in self.doms.items():
+            b, bc = d.blk[0], d.blk[1]
+            ci, cj = b.coarse_offsets(bc)
+            last = (self.Ld == 1)
+            e = d.ec if last else d.u[1]
+            win = (max(b.i_lo, 1), min(b.i_hi, b.lnx - 1), max(b.j_lo, 1), min(b.j_hi, b.lny - 1))
+            with self._ph("legs"):
+                if dst is None:
+                    res = self.ops.up_leg(self.smk, self._f0(d, src), d.rhs[0], d.u[0], e, b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides,
+                                          hx, hy, self.omega, self.coeff, self.post, (b.gx0 + b.gy0) & 1, win)
+                else:
+                    res = self.ops.span_leg(self.smk, self._f0(d, src), d.rhs[0], d.u[0], self._f0(d, dst), e, d.rc if last else d.rhs[1],
+                                            b.lnx, b.lny, bc.lnx, bc.lny, ci, cj, b.sides, hx, hy, self.omega, self.coeff, self.post,
+                                            self.pre, (b.gx0 + b.gy0) & 1, win)
+            parts[r] = self._add(res, d.ring_sumsq)
+        self._last_norm_parts = parts
+
+    def _cycle_span_eager(self):
+        """one cycle of the spanning scheme through the Python driver (the order of operations the plans replay)"""
+        self._ensure_third()
+        if self._pre is None:
+            self._sp_front("t")
+            self._sp_lower("t")
+            self._pre = "t"
+        if self.speculate:                           # the next cycle's front part goes out with this cycle's back part
+            dst = "s" if self._pre == "t" else "t"
+            self._sp_legs(self._pre, dst)
+            parts = self._last_norm_parts
+            self._sp_lower(dst)
+            self._last_norm_parts = parts
+            self._pre = dst
+        else:
+            self._sp_legs(self._pre, None)
+            self._pre = None
+
+    def _cycle_fused(self, l, zero_u, first_visit_rhs=False):
+        """Two launches and (at most) two exchanges per level.  Validity bookkeeping (m = cells of the ghost zone that
+        are exact, counted from the owned cells outwards; G = 7): after an exchange m = 7; the down leg's two sweeps
+        leave the iterate exact on m = 5, its restriction is exact on all owned coarse cells; the correction that
+        comes back from below is exact on m_c >= 3 coarse cells = 6 fine cells, so after the up leg (prolongation,
+        two sweeps) m = min(5, 6) - 2 = 3 >= 0, and the norm (one more cell) only reads exact values."""
+        hx, hy = self.h[l]
+        last = (l + 1 == self.Ld)
+        # What this level's down leg is waiting for: the iterate's ghost zone (level 0 every cycle; coarser levels only
+        # when re-visited by a W / F cycle) and, below level 0, the ghost zone of the rhs the level above just produced.
+        pending = []
+        if not zero_u:
+            pending.append("u")
+        if l > 0 and first_visit_rhs:
+            pending.append("rhs")
+
+        self._down_legs(l, zero_u, pending)
         for d in self.doms.values():
             d.u[l], d.t[l] = d.t[l], d.u[l]
         if last:
@@ -972,6 +1223,8 @@ class DistributedMultigrid:
                 d.u[0][:b.lnx, :b.lny] = torch.as_tensor(np.ascontiguousarray(u0_of_block(b), dtype=self.ldt[0])).to(d.u[0].device)
             if d.t[0] is not None:
                 d.t[0].copy_(d.u[0])
+            if d.s[0] is not None:
+                d.s[0].copy_(d.u[0])
             if self.mode == "fused":
                 # boundary ring of every coarse rhs = injected ring of f (r = f on boundary cells), once per rhs;
                 # sum of f^2 over the physical boundary cells of the exclusive window, for the norm
@@ -1004,7 +1257,7 @@ class DistributedMultigrid:
     def residual_norm(self):
         hx, hy = self.h[0]
         if self._norm_pending:
-            self._norm_value = self._plan_back.wait()
+            self._norm_value = (self._norm_plan or self._plan_back).wait()
             self._norm_pending = False
         if self._norm_value is not None:            # a native cycle brought the sum back with it
             return math.sqrt(hx * hy * self._norm_value)
@@ -1061,8 +1314,10 @@ class DistributedMultigrid:
                 # the ping-pong partner only needs the outermost ring (Dirichlet values on physical edges; the legs rewrite
                 # everything inside it)
                 u, t = d.u[0], d.t[0]
-                t[0, :b.lny].copy_(u[0, :b.lny]); t[b.lnx - 1, :b.lny].copy_(u[b.lnx - 1, :b.lny])
-                t[:b.lnx, 0].copy_(u[:b.lnx, 0]); t[:b.lnx, b.lny - 1].copy_(u[:b.lnx, b.lny - 1])
+                for t in (d.t[0], d.s[0]):
+                    if t is not None:
+                        t[0, :b.lny].copy_(u[0, :b.lny]); t[b.lnx - 1, :b.lny].copy_(u[b.lnx - 1, :b.lny])
+                        t[:b.lnx, 0].copy_(u[:b.lnx, 0]); t[:b.lnx, b.lny - 1].copy_(u[:b.lnx, b.lny - 1])
         self._last_norm_parts = None
         self._norm_value = None
 

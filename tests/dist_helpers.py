@@ -172,6 +172,18 @@ class NumpyOps:
         w = r[max(i_lo, 1):min(i_hi, lnx - 1), max(j_lo, 1):min(j_hi, lny - 1)].astype(np.float64)
         return torch.tensor([float(np.sum(w * w))], dtype=torch.float64)
 
+    span_min_cells = 1100 * 1100          # as the library: blocks above ~1100^2 cells (tests lower it to reach the path on small grids)
+
+    def span_ok(self, sm, u, e_c, lnx, lny):
+        return sm == 0 and u.dtype == e_c.dtype and lnx * lny > self.span_min_cells
+
+    def span_leg(self, sm, u, rhs, out_mid, out_next, e_c, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff,
+                 nsweep_post, nsweep_pre, poff, window):
+        """the library's spanning leg = its up leg followed by its down leg (same bits)"""
+        res = self.up_leg(sm, u, rhs, out_mid, e_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, sides, hx, hy, omega, coeff, nsweep_post, poff, window)
+        self.down_leg(sm, out_mid, rhs, out_next, rhs_c, lnx, lny, lnxc, lnyc, ci_off, cj_off, hx, hy, omega, coeff, nsweep_pre, False, poff)
+        return res
+
     def inject_ring(self, fine, coarse, lnxf, lnyf, lnxc, lnyc, sides, ci_off, cj_off):
         f, c = self._v(fine, lnxf, lnyf), self._v(coarse, lnxc, lnyc)
         for side, rows, cols in ((SIDE_ILO, [0], range(lnyc)), (SIDE_IHI, [lnxc - 1], range(lnyc)),

@@ -1,0 +1,87 @@
+"""The spanning scheme of the decomposed driver with the REAL kernels (mg_dev_span_leg) on one GPU, virtual ranks: blocks of
+more than ~1100^2 cells so that the library's spanning leg serves them.  Native plans (front / mid / back, recorded part by
+part) against the eager Python driver and against the single-GPU engine: owned cells bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import mixed_precision_multigrid_solvers_for_pdes_amd as mg                     # noqa: E402
+from mixed_precision_multigrid_solvers_for_pdes_amd import _lib                  # noqa: E402
+from mixed_precision_multigrid_solvers_for_pdes_amd import distributed as D      # noqa: E402
+import dist_helpers as H                                                           # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_reference(NX, NY, rhs, u0, cyc, dtype, managed, ncyc):
+    prec = (_lib.MG_PREC_SINGLE_MANAGED if managed else _lib.MG_PREC_SINGLE) if dtype == np.float32 else _lib.MG_PREC_DOUBLE
+    eng = mg.MultigridEngine(NX, NY, max_levels=mg.default_max_levels(NX, NY), cycle=cyc, smoother=_lib.MG_JACOBI, omega=0.8, precision=prec,
+                             speculate=1)
+    eng.set_rhs(rhs); eng.set_solution(u0)
+    hist = []
+    for _ in range(ncyc):
+        eng.cycle(1); hist.append(eng.residual_norm())
+    u = eng.get_solution(dtype)
+    eng.close()
+    return u, hist
+
+
+@pytest.mark.parametrize("px,py,NX,NY,agg,cyc,dtype,overlap", [
+    (2, 1, 2561, 1281, 321, "V", np.float64, True),
+    (2, 2, 2561, 2561, 641, "V", "managed32", True),
+    (1, 2, 1281, 2561, 321, "W", np.float64, False),
+    (2, 2, 2561, 2561, 321, "V", np.float32, False),
+])
+def test_spanning_scheme_native_equals_eager_equals_single_engine(px, py, NX, NY, agg, cyc, dtype, overlap):
+    import torch
+    managed = dtype == "managed32"
+    fdt = np.float32 if managed else dtype
+    rng = np.random.default_rng(NX + 3 * NY)
+    rhs = rng.standard_normal((NX, NY)).astype(fdt)
+    u0 = rng.standard_normal((NX, NY)).astype(fdt)
+    pattern = (True, True, True, False, True, True)           # mid, mid, mid, back, (front) mid, mid
+    u_ref, h_ref = _engine_reference(NX, NY, rhs, u0, cyc, fdt, managed, len(pattern))
+    out = {}
+    for native in (False, True):
+        ops = D.HipOps(fdt, torch.device("cuda", 0), managed_single=managed)
+        s = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, cycle=cyc, smoother="jacobi", omega=0.8, agglomerate_at=agg,
+                                   overlap=overlap, native=native, span=True)
+        assert s.native == native and s._span_usable() and s.Ld >= 1
+        s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+        hist = []
+        for spec in pattern:
+            s.speculate = spec
+            s.cycle(0); hist.append(s.residual_norm())
+        s._settle()
+        first = H.assemble(s, NX, NY, fdt)
+        # a second problem on the same solver: every plan is replayed, none recorded
+        before = s.native_cycles
+        s.set_problem(lambda b: rhs[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny], lambda b: u0[b.gx0:b.gx0 + b.lnx, b.gy0:b.gy0 + b.lny])
+        hist2 = []
+        for spec in pattern:
+            s.speculate = spec
+            s.cycle(0); hist2.append(s.residual_norm())
+        s._settle()
+        if native:
+            assert s.native_cycles == before + len(pattern), (s.native_cycles, before, s.native_failure)
+            assert set(s._sp_plans) == {("mid", "t"), ("mid", "s"), ("back", "s"), ("back", "t")} or len(s._sp_plans) >= 3
+        out[native] = (hist, first, hist2, H.assemble(s, NX, NY, fdt))
+        s.close()
+    assert out[True][0] == out[False][0] and out[True][2] == out[False][2] and out[True][0] == out[True][2]
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    np.testing.assert_array_equal(out[True][3], out[True][1])
+    np.testing.assert_array_equal(out[True][1], u_ref)
+    np.testing.assert_allclose(out[True][0], h_ref, rtol=1e-12)
+
+
+def test_span_leg_entry_point_refuses_what_it_does_not_serve():
+    lib = _lib.load()
+    assert lib.mg_dev_span_leg_ok(_lib.MG_JACOBI, 1, 1, 1, 2049, 2049) == 1
+    assert lib.mg_dev_span_leg_ok(_lib.MG_RBGS, 1, 1, 1, 2049, 2049) == 0          # red-black GS: two legs
+    assert lib.mg_dev_span_leg_ok(_lib.MG_JACOBI, 1, 0, 1, 2049, 2049) == 0        # fine and coarse field of one dtype
+    assert lib.mg_dev_span_leg_ok(_lib.MG_JACOBI, 1, 1, 1, 513, 513) == 0          # small blocks: two legs
