@@ -65,7 +65,7 @@ def main():
             b, full = s.local_solution(r)
             u.append(full[b.i_lo:b.i_hi, b.j_lo:b.j_hi].copy())
         out[native] = (hist, u)
-        plans = [q for q in (s._plan, s._plan_back) if q]
+        plans = s._all_plans()
         copies = tuple(sum(q.copy_launches()[k] for q in plans) for k in (0, 1))
         nops = sum(q.n for q in plans)
         print(f"native={native}: {px}x{py} virtual ranks, {n}^2 each, Ld={s.Ld}: {dt*1e3:.3f} ms/cycle -> {dt*1e3/(px*py):.3f} ms per rank-cycle"
