@@ -58,7 +58,7 @@ def test_plan_op_layout_and_codes_match_header():
     assert [f[0] for f in _lib.MgPlanOp._fields_] == ["op", "stream", "i", "d", "p"]
     assert C.sizeof(_lib.MgPlanOp) == 4 + 4 + 24 * 4 + 4 * 8 + 8 * 8
     codes = dict((n, int(v)) for n, v in re.findall(r"(MG_PLAN_[A-Z0-9_]+) = (\d+)", hdr))
-    assert len(codes) == 16
+    assert len(codes) == 17
     for name, value in codes.items():
         assert getattr(_lib, name) == value, name
 
