@@ -166,7 +166,9 @@ __device__ __forceinline__ void rb_leg_body(const T* __restrict__ u, const T* __
   constexpr int PH = S::RI / 2 + 2, PW = S::RJ / 2 + 2;
   constexpr int kRowPar = (1 - HALO) & 1;                           // parity of the region's first row (tiles start on odd rows, TI even)
   const int ri0 = i0 - HALO, rj0 = j0 - S::HL * N;                  // global coords of region cell (0, 0); rj0 is even
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // the wave index as a SCALAR (it is uniform, but derived from threadIdx the compiler keeps it in a vector register and turns
+  // every "first / last strip row of the workgroup" test into exec-mask arithmetic): conditions on it become scalar branches
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gj0 = rj0 + lane * N;
   const int r_base = w * RPT;
   const bool col_in = INT || (gj0 >= 0 && gj0 < a.nyv);
