@@ -1774,6 +1774,8 @@ def _bench_ranks(args, rank, local_rank, world, backend, ops_spec, on_gpu, torch
             "driver": {"native_plan_cycles": native_cycles, "python_cycles": K - native_cycles,
                        "fallback": next((x.native_failure for x in solvers.values() if x.native_failure), None),
                        "rccl_comm_ranks": comm_ranks,
+                       # level-0 up legs of cycle k + down legs of cycle k + 1 as one launch per block (MG_DIST_SPAN=0: two)
+                       "spanning_scheme": {name: bool(x._span_usable()) for name, x in solvers.items()},
                        "rccl_multi_rank_replay": ("exercised in this run" if (native_cycles > 0 and world > 1 and backend == "nccl") else
                                                   "not exercised (no multi-rank RCCL plan ran here)"),
                        "selfcheck": checks},

@@ -349,6 +349,7 @@ def test_bench_py_gpus_2_launches_its_own_ranks():
     drv = d["driver"]
     assert drv["native_plan_cycles"] == 0 and drv["python_cycles"] == 3 and drv["fallback"] is None      # gloo: no RCCL plans
     assert drv["rccl_multi_rank_replay"].startswith("not exercised")
+    assert drv["spanning_scheme"] and not any(drv["spanning_scheme"].values())     # follows the native plans: off in this rehearsal
     assert all(c["ran"] is False for c in drv["selfcheck"].values())               # nothing to replay on this backend
     ph = d["phases_ms_per_cycle"]
     for k in ("legs", "halo_copy", "halo_exchange", "coarse_allgather", "replicated_engine", "allreduce"):
