@@ -368,7 +368,12 @@ def main():
         "dtype": ("f64" if f32_cycles == 0 else "f32" if f64_cycles == 0 else "f32->f64") + " (adaptive policy)", "data": "synthetic",
         "config": {"workload": f"2D Poisson {n}^2 adaptive fp32->fp64 (switch_threshold=1e-6), V(2,2) weighted-Jacobi "
                                f"omega=0.8, {levels} levels, 1xMI355X", "grid": [n, n], "levels": levels,
-                   "cycle": "V(2,2)", "smoother": "jacobi", "parallelism": "1 GPU"},
+                   "cycle": "V(2,2)", "smoother": "jacobi", "parallelism": "1 GPU",
+                   # engine defaults of this run (include/mghip.h, mg_config): the up leg of cycle k and the down leg of cycle k + 1
+                   # of the finest level are one launch; the 5 x 5 coarsest grid is solved directly (within 1e-12 of the reference's
+                   # iteration to coarse_tol); the coarse levels from 65^2 down run in one register-resident workgroup
+                   "engine": {"speculate": int(eng.cfg.speculate), "coarse_direct": int(eng.cfg.coarse_direct), "tail": int(eng.cfg.tail),
+                              "fused": int(eng.cfg.fused)}},
         "cycles_fp32": f32_cycles, "cycles_fp64": f64_cycles,
         "residual_initial": r0, "residual_first": hist[0], "residual_last": hist[-1],
         "iterations": K,
