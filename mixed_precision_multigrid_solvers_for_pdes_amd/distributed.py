@@ -488,6 +488,8 @@ class DistributedMultigrid:
         self._sp_plans = {}                      # ... its recorded plans: ("mid", src) -> (legs + norm, lower levels), ("back", src) -> plan
         self._norm_plan = None                   # the plan whose RESULT (sum of r^2) is in flight
         self._plan_x = {}                        # plan -> halo exchanges it issues (statistics)
+        self._plan_kind = None                   # which scheme self._plan belongs to: "plain" (front | back) or "span"
+        self._plan_failure = None                # why the last recorded part has no plan (spanning scheme)
         self.native_failure = None               # why "auto" fell back to the Python driver, if it did
         self._plan_exchanges = 0
         self._rec = None                         # PlanRecorder while the first cycle is being recorded
@@ -822,7 +824,7 @@ class DistributedMultigrid:
         legs + norm | exchange + lower levels) and a back plan (up legs + norm).  Each is recorded from the Python driver the
         first time its turn comes (that cycle runs eagerly) and replayed afterwards; the norm travels behind the legs' plan."""
         torch = self.torch
-        if self._plan is not None and getattr(self, "_plan_kind", None) != "span":      # plans of the two-launch scheme
+        if self._plan is not None and self._plan_kind != "span":      # plans of the two-launch scheme
             self._settle()
             self._drop_plan()
         self._ensure_third()
@@ -896,7 +898,7 @@ class DistributedMultigrid:
         from . import dist_plan
         torch = self.torch
         state = self._pointer_state()
-        if self._plan is not None and (self._plan_state != state or getattr(self, "_plan_kind", None) == "span"):
+        if self._plan is not None and (self._plan_state != state or self._plan_kind == "span"):
             self._settle()
             self._drop_plan()
         self._plan_kind = "plain"
