@@ -99,7 +99,8 @@ typedef struct mg_config {
                                 between the two cycles is written (unless tol <= 0 and no precision switch is pending: nothing
                                 can end the solve there) but never read back.  Same iterates bit for bit; the norm's partial
                                 sums are taken over other tiles (last-bit differences).  0: strictly one cycle at a time */
-  int32_t coarse_direct;     /* 1 (with fused and tail, a 5 x 5 coarsest grid): the nine-unknown coarsest system is solved
+  int32_t coarse_direct;     /* 1 (with fused and tail, a coarsest grid of at most 64 unknowns: the 5 x 5 of every 2^k + 1 square --
+                                nine --, the 9 x 5 of a 2:1 domain -- 21 --, ...): the coarsest system is solved
                                 directly (u = A^-1 f, the inverse formed on the host) instead of by the reference's Gauss-Seidel
                                 iteration to coarse_tol (solvers/multigrid.py:119-124, 355-370).  NOT bit-identical to the
                                 reference: the two differ by at most ||A_c^-1|| coarse_tol / h_c ~ 2e-13 per coarsest visit (the

@@ -114,6 +114,8 @@ struct mg_handle {
   int tail_nops = 0;
   bool tail_direct = false;        // cfg.coarse_direct applies: 5 x 5 coarsest grid inside the tail; tail_minv is its inverse
   double tail_minv[81] = {0};
+  double* d_minv = nullptr;        // a coarsest grid other than 5 x 5 with <= 64 unknowns: its n x n inverse on the device (LDS tail)
+  int minv_n = 0;
   double tail_minv_sigma = -1.0;   // the shift tail_minv was built for (rebuilt when mg_set_shift changes it)
   std::string err;
   std::vector<double> adapt_hist;

@@ -1310,6 +1310,8 @@ struct TailArgs {
   int direct;                  // 1: the 5 x 5 coarsest system (nine unknowns, zero ring) is solved by u = minv f instead of the
                                // reference's Gauss-Seidel iteration to coarse_tol (mg_config.coarse_direct; not bit-identical)
   double minv[81];             // inverse of the 9 x 9 coarsest matrix, row-major (host, long double elimination)
+  const double* minv_dev;      // any other coarsest grid with n = (nx - 2) (ny - 2) <= 64 unknowns (the 9 x 5 of a 2:1 domain, ...): its
+  int minv_n;                  // n x n inverse in device memory, row-major, unknown (i, j) at (i - 1) (ny - 2) + (j - 1)
 };
 
 // variable coefficient: the relaxed value of cell idx from the vertex values `A` (varcoef_kernel's expressions)
@@ -1515,6 +1517,21 @@ __global__ __launch_bounds__(kTailBlock) void coarse_tail_kernel(const T* __rest
             acc += a.minv[li * 9 + j] * fj;
           }
           if (lane < 9) su[g] = (TCO)acc;
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0 && sweeps_out) *sweeps_out = 0;
+        } else if (a.direct && a.minv_dev && a.minv_n == (nx - 2) * (ny - 2)) {
+          // the same for any coarsest grid of at most 64 unknowns (one per lane): row `lane` of the inverse streams from memory
+          const int n = a.minv_n, my = ny - 2;
+          const int li = lane < n ? lane : 0;
+          const int g = (li / my + 1) * ny + (li % my) + 1;
+          const double fv = (double)sf[g];
+          const double* __restrict__ row = a.minv_dev + (size_t)li * n;
+          double acc = 0.0;
+          for (int j = 0; j < n; ++j) {
+            const double fj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(fv), j), __builtin_amdgcn_readlane(__double2loint(fv), j));
+            acc += row[j] * fj;
+          }
+          if (lane < n) su[g] = (TCO)acc;
           __builtin_amdgcn_wave_barrier();
           if (lane == 0 && sweeps_out) *sweeps_out = 0;
         } else if (nx * ny <= kPipeCells && (nx + ny - 5) / 2 + 2 <= kPipeSlots) {

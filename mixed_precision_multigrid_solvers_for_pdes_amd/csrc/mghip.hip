@@ -723,6 +723,7 @@ void release(mg_handle* h) {
   if (h->partials) (void)hipFree(h->partials);
   if (h->d_scalar) (void)hipFree(h->d_scalar);
   if (h->d_int) (void)hipFree(h->d_int);
+  if (h->d_minv) (void)hipFree(h->d_minv);
   if (h->staging) (void)hipFree(h->staging);
   if (h->mbox) (void)hipHostFree(h->mbox);
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
@@ -858,7 +859,8 @@ int tail_set_attr(size_t bytes) {
 // coarsest level 2^(L-1) times per cycle and spent most of their time in that iteration; a V-cycle saves its ~20 sweeps.
 bool want_direct(const mg_handle* h) {
   const int L = h->L();
-  if (h->lv[L - 1].nx != 5 || h->lv[L - 1].ny != 5) return false;
+  const int n = (h->lv[L - 1].nx - 2) * (h->lv[L - 1].ny - 2);          // unknowns of the coarsest grid: 9 for the 5 x 5 of every
+  if (n < 1 || n > 64) return false;                                    // 2^k + 1 square, 21 for the 9 x 5 of a 2:1 domain
   return h->cfg.coarse_direct != 0;
 }
 
@@ -915,47 +917,60 @@ int plan_tail_lds(mg_handle* h) {
 // zero ring (a == 1 without a coefficient field).  Gaussian elimination with partial pivoting in long double.
 int build_coarse_inverse(mg_handle* h) {
   const Level& v = h->lv[h->L() - 1];
-  double a[25];
-  for (double& x : a) x = 1.0;
+  const int cnx = v.nx, cny = v.ny, my = cny - 2, n = (cnx - 2) * my;
+  if (n < 1 || n > 64) return fail(&h->err, MG_ERR_INVALID_VALUE, "coarse_direct: the coarsest grid has more than 64 unknowns");
+  std::vector<double> a((size_t)cnx * cny, 1.0);
   if (h->varcoef) {
     const int dt = h->grid_dtype;
-    std::vector<unsigned char> buf((size_t)5 * v.ld[dt] * esize(dt));
+    std::vector<unsigned char> buf((size_t)cnx * v.ld[dt] * esize(dt));
     HIPC(&h->err, hipMemcpyAsync(buf.data(), v.a[dt], buf.size(), hipMemcpyDeviceToHost, h->stream));
     HIPC(&h->err, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < 5; ++i)
-      for (int j = 0; j < 5; ++j)
-        a[i * 5 + j] = dt == MG_F32 ? (double)reinterpret_cast<const float*>(buf.data())[(size_t)i * v.ld[dt] + j]
-                                    : reinterpret_cast<const double*>(buf.data())[(size_t)i * v.ld[dt] + j];
+    for (int i = 0; i < cnx; ++i)
+      for (int j = 0; j < cny; ++j)
+        a[(size_t)i * cny + j] = dt == MG_F32 ? (double)reinterpret_cast<const float*>(buf.data())[(size_t)i * v.ld[dt] + j]
+                                              : reinterpret_cast<const double*>(buf.data())[(size_t)i * v.ld[dt] + j];
   }
   const long double ihx2 = 1.0L / ((long double)v.hx * v.hx), ihy2 = 1.0L / ((long double)v.hy * v.hy);
-  long double M[9][18];
-  for (int p = 0; p < 9; ++p) {
-    for (int q = 0; q < 18; ++q) M[p][q] = (q == 9 + p) ? 1.0L : 0.0L;
-    const int i = p / 3 + 1, j = p % 3 + 1;
-    const long double c = a[i * 5 + j];
-    const long double aip = 0.5L * (c + a[(i + 1) * 5 + j]), aim = 0.5L * (c + a[(i - 1) * 5 + j]);
-    const long double ajp = 0.5L * (c + a[i * 5 + j + 1]), ajm = 0.5L * (c + a[i * 5 + j - 1]);
-    M[p][p] = (aip + aim) * ihx2 + (ajp + ajm) * ihy2 + (long double)h->sigma;
-    if (i < 3) M[p][p + 3] = -aip * ihx2;
-    if (i > 1) M[p][p - 3] = -aim * ihx2;
-    if (j < 3) M[p][p + 1] = -ajp * ihy2;
-    if (j > 1) M[p][p - 1] = -ajm * ihy2;
+  const int w = 2 * n;
+  std::vector<long double> M((size_t)n * w, 0.0L);      // [A | I], unknown (i, j) at p = (i - 1) my + (j - 1)
+  for (int p = 0; p < n; ++p) {
+    M[(size_t)p * w + n + p] = 1.0L;
+    const int i = p / my + 1, j = p % my + 1;
+    const long double c = a[(size_t)i * cny + j];
+    const long double aip = 0.5L * (c + a[(size_t)(i + 1) * cny + j]), aim = 0.5L * (c + a[(size_t)(i - 1) * cny + j]);
+    const long double ajp = 0.5L * (c + a[(size_t)i * cny + j + 1]), ajm = 0.5L * (c + a[(size_t)i * cny + j - 1]);
+    M[(size_t)p * w + p] = (aip + aim) * ihx2 + (ajp + ajm) * ihy2 + (long double)h->sigma;
+    if (i < cnx - 2) M[(size_t)p * w + p + my] = -aip * ihx2;
+    if (i > 1) M[(size_t)p * w + p - my] = -aim * ihx2;
+    if (j < my) M[(size_t)p * w + p + 1] = -ajp * ihy2;
+    if (j > 1) M[(size_t)p * w + p - 1] = -ajm * ihy2;
   }
-  for (int c = 0; c < 9; ++c) {
+  for (int c = 0; c < n; ++c) {
     int piv = c;
-    for (int r = c + 1; r < 9; ++r) if (fabsl(M[r][c]) > fabsl(M[piv][c])) piv = r;
-    if (M[piv][c] == 0.0L) return fail(&h->err, MG_ERR_INVALID_VALUE, "coarse_direct: singular coarsest system");
-    if (piv != c) for (int q = 0; q < 18; ++q) std::swap(M[piv][q], M[c][q]);
-    const long double d = 1.0L / M[c][c];
-    for (int q = 0; q < 18; ++q) M[c][q] *= d;
-    for (int r = 0; r < 9; ++r) {
-      if (r == c || M[r][c] == 0.0L) continue;
-      const long double f = M[r][c];
-      for (int q = 0; q < 18; ++q) M[r][q] -= f * M[c][q];
+    for (int r = c + 1; r < n; ++r) if (fabsl(M[(size_t)r * w + c]) > fabsl(M[(size_t)piv * w + c])) piv = r;
+    if (M[(size_t)piv * w + c] == 0.0L) return fail(&h->err, MG_ERR_INVALID_VALUE, "coarse_direct: singular coarsest system");
+    if (piv != c) for (int q = 0; q < w; ++q) std::swap(M[(size_t)piv * w + q], M[(size_t)c * w + q]);
+    const long double d = 1.0L / M[(size_t)c * w + c];
+    for (int q = 0; q < w; ++q) M[(size_t)c * w + q] *= d;
+    for (int r = 0; r < n; ++r) {
+      if (r == c || M[(size_t)r * w + c] == 0.0L) continue;
+      const long double f = M[(size_t)r * w + c];
+      for (int q = 0; q < w; ++q) M[(size_t)r * w + q] -= f * M[(size_t)c * w + q];
     }
   }
-  for (int p = 0; p < 9; ++p)
-    for (int q = 0; q < 9; ++q) h->tail_minv[p * 9 + q] = (double)M[p][9 + q];
+  if (n == 9) {
+    for (int p = 0; p < 9; ++p)
+      for (int q = 0; q < 9; ++q) h->tail_minv[p * 9 + q] = (double)M[(size_t)p * w + 9 + q];
+  }
+  if (cnx != 5 || cny != 5) {      // the LDS tail streams the rows of the inverse from device memory
+    std::vector<double> inv((size_t)n * n);
+    for (int p = 0; p < n; ++p)
+      for (int q = 0; q < n; ++q) inv[(size_t)p * n + q] = (double)M[(size_t)p * w + n + q];
+    if (!h->d_minv) HIPC(&h->err, hipMalloc((void**)&h->d_minv, sizeof(double) * 64 * 64));
+    HIPC(&h->err, hipStreamSynchronize(h->stream));                  // no launch in flight reads the old inverse
+    HIPC(&h->err, hipMemcpy(h->d_minv, inv.data(), sizeof(double) * inv.size(), hipMemcpyHostToDevice));
+    h->minv_n = n;
+  }
   h->tail_minv_sigma = h->sigma;
   return MG_OK;
 }
@@ -975,6 +990,8 @@ int launch_tail(mg_handle* h, bool zero_top) {
     if (h->tail_minv_sigma != h->sigma) { const int rc = build_coarse_inverse(h); if (rc != MG_OK) return rc; }
     a.direct = 1;
     std::memcpy(a.minv, h->tail_minv, sizeof(a.minv));
+    const Level& cl = h->lv[L - 1];
+    if (cl.nx != 5 || cl.ny != 5) { a.minv_dev = h->d_minv; a.minv_n = h->minv_n; }
   }
   const bool var = h->varcoef;
   const size_t extra = var ? 1 : 0;

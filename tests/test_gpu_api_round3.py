@@ -244,6 +244,27 @@ def test_default_coarsest_solve_is_direct_and_the_iteration_can_be_asked_for():
             e.close()
 
 
+@pytest.mark.parametrize("nx,ny,dom", [(129, 65, (0.0, 2.0, 0.0, 1.0)), (65, 129, (0.0, 1.0, 0.0, 2.0)), (257, 129, (0.0, 1.0, 0.0, 1.0)), (49, 25, (0.0, 2.0, 0.0, 1.0))])
+@pytest.mark.parametrize("cyc,kind", [("V", _lib.MG_JACOBI), ("W", _lib.MG_RBGS)])
+def test_direct_coarsest_solve_on_grids_that_do_not_end_in_5x5(nx, ny, dom, cyc, kind):
+    """A 2:1 grid ends in 9 x 5 (21 unknowns), 49 x 25 in 7 x 4 (10): the LDS tail solves any coarsest grid of at most 64 unknowns
+    directly from its inverse in device memory; iterates stay within 1e-12 of the reference's iteration, histories within
+    max(1e-9 relative, coarse_tolerance absolute) -- the bar of the 5 x 5 case"""
+    x = np.linspace(dom[0], dom[1], nx); y = np.linspace(dom[2], dom[3], ny)
+    f = np.sin(np.pi * x / dom[1])[:, None] * np.sin(np.pi * y / dom[3])[None, :] + 0.05 * np.random.default_rng(nx).standard_normal((nx, ny))
+    res = {}
+    for direct in (False, "auto"):
+        e = mg.MultigridEngine(nx, ny, domain=dom, max_levels=mg.default_max_levels(nx, ny), cycle=cyc, smoother=kind,
+                               omega=0.8 if kind == _lib.MG_JACOBI else 1.0, coarse_direct=direct)
+        assert e.shapes[-1] != (5, 5) and (e.shapes[-1][0] - 2) * (e.shapes[-1][1] - 2) <= 64
+        u, r = e.solve(f, tol=0.0, max_iterations=6)
+        res[direct] = (u, r)
+        e.close()
+    assert res["auto"][1]["last_coarse_sweeps"] == 0 and res[False][1]["last_coarse_sweeps"] > 0
+    assert np.max(np.abs(res["auto"][0] - res[False][0])) <= 1e-12 * np.max(np.abs(res[False][0]))
+    np.testing.assert_allclose(res["auto"][1]["residual_history"], res[False][1]["residual_history"], rtol=1e-9, atol=1e-12)
+
+
 # ---------------------------------------------------------------- ADVICE r02 ----
 def test_fmg_under_defect_correction_is_used_not_discarded():
     """with MG_PREC_DEFECT the FMG guess was built in the fp32 hierarchy and thrown away.  Now the FMG pass runs
