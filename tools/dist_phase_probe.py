@@ -2,7 +2,7 @@
 """Decomposed solve loop (DecomposedSolve, what bench.py --gpus N runs) with virtual ranks on ONE GPU: per-rank-cycle time and
 the per-phase device times of a replayed cycle, beside the single-domain engine on one block.
 
-    python3 tools/dist_phase_probe.py px py n [float64|float32] [cycles]
+    python3 tools/dist_phase_probe.py px py n [float64|float32] [cycles] [agglomerate_at]
 """
 import os
 import sys
@@ -18,10 +18,11 @@ from mixed_precision_multigrid_solvers_for_pdes_amd import distributed as D, _li
 px, py, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 dtype = np.dtype(sys.argv[4]) if len(sys.argv) > 4 else np.dtype(np.float64)
 K = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+AGG = int(sys.argv[6]) if len(sys.argv) > 6 else 1025
 NX, NY = px * (n - 1) + 1, py * (n - 1) + 1
 dom = (0.0, float(px), 0.0, float(py))
 ops = D.HipOps(dtype, torch.device("cuda", 0), managed_single=(dtype == np.float32))
-sv = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, domain=dom, smoother="jacobi", omega=0.8, native=True)
+sv = D.DistributedMultigrid(NX, NY, px, py, range(px * py), ops, None, domain=dom, smoother="jacobi", omega=0.8, native=True, agglomerate_at=AGG)
 solve = D.DecomposedSolve({"f64" if dtype == np.float64 else "f32": sv}, "fixed")
 solve.set_problem(lambda b: D.sine_rhs_block(b, dom))
 solve.run(0.0, 4)
@@ -29,7 +30,7 @@ solve.set_problem(lambda b: D.sine_rhs_block(b, dom))
 torch.cuda.synchronize(); t0 = time.perf_counter()
 hist, _, _ = solve.run(0.0, K)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-print(f"{px}x{py} virtual ranks of {n}^2 {dtype.name}: {dt * 1e3:.3f} ms per cycle = {dt * 1e3 / (px * py):.3f} ms per rank-cycle "
+print(f"agglomerate_at {AGG} (Ld = {sv.Ld}): {px}x{py} virtual ranks of {n}^2 {dtype.name}: {dt * 1e3:.3f} ms per cycle = {dt * 1e3 / (px * py):.3f} ms per rank-cycle "
       f"({px * py * n * n / dt / 1e9:.1f} GDoF/s on this one GPU), native cycles {sv.native_cycles}, ||r|| -> {hist[-1]:.3e}")
 sv.profile_phases(True)
 solve.run(0.0, 5)
