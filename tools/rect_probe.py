@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""V(2,2) weighted-Jacobi cycle times of square and 2:1 hierarchies (fp64), with the direct coarsest solve (default) and the
+reference's iteration: 2:1 grids end in 9 x 5 / 5 x 9 and run the LDS tail -- what the replicated coarse engine of a 2 x 1 or
+4 x 2 decomposition solves every cycle.    python3 tools/rect_probe.py"""
 import sys, numpy as np
 sys.path.insert(0, ".")
 import mixed_precision_multigrid_solvers_for_pdes_amd as mg
