@@ -28,7 +28,9 @@
 //   * levels of one wave (17^2, 9^2, 5^2) synchronise with wave-level fences only: the other waves wait at the next
 //     workgroup barrier of the level above;
 //   * the 5 x 5 solve is lexgs_5x5_zero_ring (mg_kernels.hpp: the reference's lexicographic Gauss-Seidel to coarse_tol,
-//     bit for bit) or, mg_config.coarse_direct, u = A^-1 f.
+//     bit for bit) or, mg_config.coarse_direct, u = A^-1 f;
+//   * variable coefficients (VAR, from 33^2 down): the face means of a lane's cells and their reciprocal diagonal are formed
+//     once per launch from the levels' coefficient / rdiag fields and live in registers beside the iterate (T2Coef).
 //
 // Arithmetic per cell: the expressions of the single-operator kernels in the same order (solvers/smoothers.py:62-84,
 // 175-207; operators/laplacian.py:73-77; operators/transfer.py:100-124, 234-267) -- results are bit-identical to
