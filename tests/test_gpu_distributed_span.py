@@ -85,3 +85,54 @@ def test_span_leg_entry_point_refuses_what_it_does_not_serve():
     assert lib.mg_dev_span_leg_ok(_lib.MG_RBGS, 1, 1, 1, 2049, 2049) == 0          # red-black GS: two legs
     assert lib.mg_dev_span_leg_ok(_lib.MG_JACOBI, 1, 0, 1, 2049, 2049) == 0        # fine and coarse field of one dtype
     assert lib.mg_dev_span_leg_ok(_lib.MG_JACOBI, 1, 1, 1, 513, 513) == 0          # small blocks: two legs
+
+
+def test_adaptive_policy_over_two_spanning_solvers_native_equals_eager():
+    """bench.py --gpus N in miniature at a block size the spanning leg serves: the adaptive policy drives an fp32 (managed) and an
+    fp64 decomposed solver through take_iterate_from while front parts are queued ahead of the norms; with recorded plans the
+    trajectory, the norms and the iterate equal the eager driver's, bit for bit, whether or not the switch is predicted."""
+    import torch
+    px, py, n = 2, 1, 1281
+    NX, NY = px * (n - 1) + 1, py * (n - 1) + 1
+    dom = (0.0, float(px), 0.0, float(py))
+    thr = 1e-3
+    out = {}
+    for native, predict in ((False, False), (False, True), (True, True), (True, False)):
+        dev = torch.device("cuda", 0)
+        solvers = {"f32": D.DistributedMultigrid(NX, NY, px, py, range(px * py), D.HipOps(np.float32, dev, managed_single=True), None,
+                                                 domain=dom, smoother="jacobi", omega=0.8, agglomerate_at=321, native=native, span=True),
+                   "f64": D.DistributedMultigrid(NX, NY, px, py, range(px * py), D.HipOps(np.float64, dev), None,
+                                                 domain=dom, smoother="jacobi", omega=0.8, agglomerate_at=321, native=native, span=True)}
+        assert all(sv._span_usable() for sv in solvers.values())
+        record = []
+        for solve in range(2):
+            for sv in solvers.values():
+                sv.set_problem(lambda b: D.sine_rhs_block(b, dom))
+            policy, rn = D.AdaptivePolicy(thr), solvers["f64"].residual_norm()
+            for _ in range(9):
+                had = policy.phase
+                now = policy.before_cycle(rn)
+                if now != had:
+                    solvers[now].take_iterate_from(solvers[had])
+                solvers[now].speculate = (not policy.switch_likely()) if predict else True
+                solvers[now].cycle(0)
+                rn = solvers[now].residual_norm()
+                policy.after_cycle(rn)
+                record.append((now, rn))
+        solvers[policy.phase]._settle()
+        u = H.assemble(solvers[policy.phase], NX, NY, np.float64)
+        if native:
+            assert solvers["f32"].native_cycles > 0 and solvers["f64"].native_cycles > 0
+        for sv in solvers.values():
+            sv.close()
+        out[(native, predict)] = (record, u)
+    phases = [p for p, _ in out[(False, False)][0]]
+    assert "f32" in phases and "f64" in phases                       # the policy did switch
+    for predict in (False, True):                                    # plans against the eager driver: the same operations, the same bits
+        assert out[(True, predict)][0] == out[(False, predict)][0]
+        np.testing.assert_array_equal(out[(True, predict)][1], out[(False, predict)][1])
+    # predicting the switch replaces a spanning leg by an up leg on the cycle before it: the same iterates, the norm of that
+    # cycle summed over other tiles (last bits)
+    assert [p for p, _ in out[(False, True)][0]] == phases
+    np.testing.assert_allclose([r for _, r in out[(False, True)][0]], [r for _, r in out[(False, False)][0]], rtol=1e-13)
+    np.testing.assert_array_equal(out[(False, True)][1], out[(False, False)][1])
