@@ -94,7 +94,7 @@ typedef struct mg_config {
                                 cycles per level (solvers/advanced_multigrid.py:626-683, gpu/gpu_solver.py:583-652) */
   int32_t speculate;         /* with fused -- 1: mg_iterate / mg_solve queue the down leg of cycle k+1 while ||r_k|| travels to
                                 the host (dropped if that norm ends the solve); 2 (the host side's default): as 1, and where the
-                                finest level is bandwidth-bound (> ~1100^2 cells, Jacobi, constant coefficients) the up leg of
+                                finest level is bandwidth-bound (> ~1100^2 cells, constant coefficients) the up leg of
                                 cycle k and that down leg are ONE launch (the spanning leg, csrc/mg_rb_kernels.hpp): the iterate
                                 between the two cycles is written (unless tol <= 0 and no precision switch is pending: nothing
                                 can end the solve there) but never read back.  Same iterates bit for bit; the norm's partial

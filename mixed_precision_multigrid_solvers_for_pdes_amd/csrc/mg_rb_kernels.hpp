@@ -34,7 +34,7 @@ namespace mg {
 #endif
 template <typename T, int HALO, int W, int RPT> struct RbShape {
   static constexpr int N = VecW<T>::N;
-  static constexpr int HL = (MG_RB_HL_MIN <= 2 && 2 * N >= HALO) ? 2 : 4;
+  static constexpr int HL = (MG_RB_HL_MIN <= 2 && 2 * N >= HALO) ? 2 : ((HALO + N - 1) / N > 4 ? (HALO + N - 1) / N : 4);   // 5 for the fp64 red-black spanning leg (halo 10)
   static constexpr int RI = W * RPT;                 // region rows
   static constexpr int RJ = 64 * N;                  // region cols (one wave = one region row segment of 1 KB)
   static constexpr int TI = RI - 2 * HALO;           // tile rows

@@ -563,13 +563,18 @@ int launch_span_rb(const void* u, const void* rhs, void* out_mid, void* out_next
   return a.ntiles;
 }
 // dt: dtype of the level and of the level below, dcomp: interpolation dtype.  -1: no spanning leg for this combination.
-int d_span(int dt, int dcomp, const void* u, const void* rhs, void* out_mid, void* out_next, const void* e_c, void* rhs_c,
-           double* partials, const LegGeom& g, int nsweep_pre, hipStream_t st) {
-  constexpr int SM = mg::kSmJacobi;
+template <int SM>
+int d_span_sm(int dt, int dcomp, const void* u, const void* rhs, void* out_mid, void* out_next, const void* e_c, void* rhs_c,
+              double* partials, const LegGeom& g, int nsweep_pre, hipStream_t st) {
   if (dt == MG_F64 && dcomp == MG_F64) return launch_span_rb<double, double, double, SM>(u, rhs, out_mid, out_next, e_c, rhs_c, partials, g, nsweep_pre, st);
   if (dt == MG_F32 && dcomp == MG_F64) return launch_span_rb<float, float, double, SM>(u, rhs, out_mid, out_next, e_c, rhs_c, partials, g, nsweep_pre, st);
   if (dt == MG_F32 && dcomp == MG_F32) return launch_span_rb<float, float, float, SM>(u, rhs, out_mid, out_next, e_c, rhs_c, partials, g, nsweep_pre, st);
   return -1;
+}
+int d_span(int dt, int dcomp, const void* u, const void* rhs, void* out_mid, void* out_next, const void* e_c, void* rhs_c,
+           double* partials, const LegGeom& g, int nsweep_pre, hipStream_t st, int sm = MG_JACOBI) {
+  return sm == MG_RBGS ? d_span_sm<mg::kSmRbgs>(dt, dcomp, u, rhs, out_mid, out_next, e_c, rhs_c, partials, g, nsweep_pre, st)
+                       : d_span_sm<mg::kSmJacobi>(dt, dcomp, u, rhs, out_mid, out_next, e_c, rhs_c, partials, g, nsweep_pre, st);
 }
 
 // One weighted-Jacobi sweep on a level above ~1100^2 cells: the register-blocked sweeps kernel with nsweep = 1 (same
@@ -1102,7 +1107,7 @@ int cycle_fused(mg_handle* h, int l, bool zero_u, int part = kPartFull) {
 // there) and the pre-smoothed iterate of the next cycle to the third buffer s.  Afterwards u = s (what the next up leg
 // reads), t = the iterate (undo_front's swap brings it back), s = the buffer just consumed.
 bool span_ok(const mg_handle* h) {
-  if (h->cfg.speculate < 2 || !h->fused() || h->L() < 3 || h->varcoef || h->cfg.smoother != MG_JACOBI) return false;
+  if (h->cfg.speculate < 2 || !h->fused() || h->L() < 3 || h->varcoef) return false;
   if (h->cfg.pre < 1 || h->cfg.pre > 2 || h->cfg.post < 1 || h->cfg.post > 2 || h->cfg.precision == MG_PREC_DEFECT) return false;
   const Level& f = h->lv[0];
   LegGeom g{f.nx, f.ny, 0, 0, 0, 0, f.hx, f.hy, 0, 0, 0, 0, true};
@@ -1129,7 +1134,7 @@ int cycle_span(mg_handle* h, bool keep_mid) {
   g.rb = rb_mode(h);
   g.nsweep = h->cfg.post;
   const int n = d_span(dt, h->grid_dtype, f.u[dt], f.rhs[dt], keep_mid ? f.t[dt] : nullptr, f.s[dt], c.u[dc], c.rhs[dc], h->partials, g,
-                       h->cfg.pre, h->stream);
+                       h->cfg.pre, h->stream, h->cfg.smoother);
   if (n < 0) return MG_ERR_INVALID_VALUE;
   void* consumed = f.u[dt];
   f.u[dt] = f.s[dt];

@@ -16,8 +16,8 @@ def _rhs(n):
     return 2 * np.pi**2 * np.sin(np.pi * x)[:, None] * np.sin(2 * np.pi * x)[None, :] + 0.05 * rng.standard_normal((n, n))
 
 
-def _run(n, prec, speculate, tol, its, pre=2, post=2, u0=None):
-    eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), cycle="V", smoother=_lib.MG_JACOBI, omega=0.8,
+def _run(n, prec, speculate, tol, its, pre=2, post=2, u0=None, smoother=_lib.MG_JACOBI, omega=0.8, cycle="V"):
+    eng = mg.MultigridEngine(n, n, max_levels=mg.default_max_levels(n, n), cycle=cycle, smoother=smoother, omega=omega,
                              precision=prec, pre=pre, post=post, speculate=speculate)
     f = _rhs(n)
     if prec == _lib.MG_PREC_SINGLE:
@@ -73,3 +73,19 @@ def test_span_with_an_initial_guess_and_the_boundary_ring():
     eng.close()
     ub, rb = _run(n, _lib.MG_PREC_DOUBLE, 1, 0.0, 3, u0=2.0 * u0)
     assert np.array_equal(ua, ub)
+
+
+@pytest.mark.parametrize("prec", [_lib.MG_PREC_DOUBLE, _lib.MG_PREC_SINGLE, _lib.MG_PREC_SINGLE_MANAGED])
+@pytest.mark.parametrize("n,omega,cycle", [(1281, 1.0, "V"), (2049, 1.15, "V"), (1281, 1.0, "W")])
+def test_red_black_gs_spanning_leg_equals_two_launch_form(n, omega, cycle, prec):
+    """red-black Gauss-Seidel: four half-sweeps + residual + restriction = a halo of 10 rows / columns per side"""
+    u1, r1 = _run(n, prec, 1, 0.0, 4, smoother=_lib.MG_RBGS, omega=omega, cycle=cycle)
+    u2, r2 = _run(n, prec, 2, 0.0, 4, smoother=_lib.MG_RBGS, omega=omega, cycle=cycle)
+    assert np.array_equal(u1, u2)
+    np.testing.assert_allclose(r2["residual_history"], r1["residual_history"], rtol=1e-12)
+    _, probe = _run(n, prec, 1, 0.0, 4, smoother=_lib.MG_RBGS, omega=omega, cycle=cycle)
+    tol = 1.5 * probe["residual_history"][2]
+    u1, r1 = _run(n, prec, 1, tol, 9, smoother=_lib.MG_RBGS, omega=omega, cycle=cycle)
+    u2, r2 = _run(n, prec, 2, tol, 9, smoother=_lib.MG_RBGS, omega=omega, cycle=cycle)
+    assert r1["converged"] and r2["converged"] and r1["iterations"] == r2["iterations"]
+    assert np.array_equal(u1, u2)
